@@ -1,0 +1,176 @@
+/*
+ * spectavi_amd.h -- C-ABI of libspectavi.so (MI355X / gfx950 build).
+ *
+ * Drop-in boundary for the descriptor-matching + DLT hot path of
+ * vvhitedog/spectavi.  Section 1 re-exports, symbol for symbol, what the
+ * reference's ctypes front-end binds (reference src/Spectavi.cpp, declared to
+ * ctypes in spectavi/feature.py and spectavi/mvg.py).  Sections 2 and 3 add
+ * status-returning variants with caller-allocated outputs (host pointers) and
+ * device-pointer variants (inputs/outputs resident in HBM, asynchronous on a
+ * caller stream) used by the benchmark, the tests and multi-GPU sharding.
+ *
+ * Conventions: row-major C-contiguous arrays, plain pointers and ints, no C++
+ * or torch types.  Nothing throws across this boundary (the reference lets
+ * std::runtime_error escape extern "C": src/BruteForceNnL1K2.h:75,79).
+ * All compute happens in hand-written HIP kernels; there is NO CPU fallback:
+ * without a usable gfx950 device every entry point fails with SPV_ERR_HIP.
+ */
+#ifndef SPECTAVI_AMD_H
+#define SPECTAVI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "NdArray.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* status                                                                    */
+/* ------------------------------------------------------------------------ */
+#define SPV_OK 0
+#define SPV_ERR_INVALID 1 /* argument rejected (dim % 16, m > 31, k != 2, NULL ...) */
+#define SPV_ERR_HIP 2     /* HIP runtime / no device / launch failure */
+#define SPV_ERR_NOMEM 3   /* host or device allocation failed */
+
+/* Status of the last call made by this thread through any entry point below
+ * (the void reference-compatible symbols report errors only this way). */
+int spv_last_status(void);
+/* Human-readable message for spv_last_status(); valid until the thread's next call. */
+const char *spv_last_error(void);
+/* Number of visible HIP devices (0 if none / no driver). */
+int spv_device_count(void);
+/* Device used by the host-pointer entry points of this process (default:
+ * environment SPECTAVI_DEVICE, else 0). */
+int spv_set_device(int device);
+/* Library version string. */
+const char *spv_version(void);
+
+/* Optional in-library kernel timing: when enabled, the hot kernels (names:
+ * "l1k2_tile", "l1k2_merge", "cascade_project", "cascade_buckets",
+ * "cascade_probe_refine", "dlt") are bracketed by hipEvents recorded on the
+ * stream they are launched on.  spv_profile_read synchronises with the
+ * recorded events and returns launch count and summed milliseconds since the
+ * last reset. */
+void spv_profile_enable(int on);
+void spv_profile_reset(void);
+int spv_profile_read(const char *kernel, long long *launches, double *total_ms);
+/* Diagnostic: sustained v_sad_hi_u8 lane-ops/s with register operands only
+ * (`blocks` workgroups of 256 lanes, `iters` x 64 SADs per lane). */
+int spv_microbench_sad(int blocks, int iters, double *lane_ops_per_s);
+
+/* ------------------------------------------------------------------------ */
+/* 1. Reference-compatible symbols (same names, argument order and meaning)  */
+/* ------------------------------------------------------------------------ */
+
+/* Exact L1 (sum |x-y|) 2-nearest-neighbour of every query row y against every
+ * database row x.  Replaces reference src/Spectavi.cpp:284-298
+ * (BruteForceNnL1K2::find_neighbours<IdentityFilter>, src/BruteForceNnL1K2.h:84-145).
+ *   x: uint8[xrows, dim] database, y: uint8[yrows, dim] queries, dim % 16 == 0.
+ *   outidx : callee-allocated size_t[yrows,2]  (col 0 = nearest)
+ *   outdist: callee-allocated int  [yrows,2]
+ * Result per query = the two smallest (dist, idx) pairs in lexicographic order;
+ * missing neighbours (xrows < 2) are (INT_MAX, (size_t)-1) as in the reference
+ * (src/BruteForceNnL1K2.h:100-103).  `nthreads` is accepted and ignored (the
+ * reference uses it as the OpenMP team size, src/BruteForceNnL1K2.h:92). */
+void nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
+                       int nthreads, NdArray *outidx, NdArray *outdist);
+
+/* Cascade-hash candidate prefilter + L1 refine.  Replaces reference
+ * src/Spectavi.cpp:321-336 (CascadingHashNn, src/CascadingHashNn.h:86-245).
+ *   x,y: float32[rows, dim], integer-valued in [-128,127]; dim % 16 == 0.
+ *   k must be 2 (the reference sizes the buffers by k but writes two columns,
+ *   src/Spectavi.cpp:329-335); hash_bit_rate m in [1,31]; num_hash_tables n >= 1;
+ *   num_candidate_neighbours g in [0, m].
+ *   outidx size_t[yrows,k], outdist float[yrows,k]; queries with fewer than two
+ *   candidates carry ((size_t)-1, 2147483648.0f) (src/CascadingHashNn.h:244).
+ * Hyperplanes: n matrices float32[dim, m] of N(0,1) drawn from std::mt19937
+ * filled dim-major (src/CascadingHashNn.h:86-100); seeded from
+ * std::random_device like the reference unless spv_set_hash_seed() /
+ * SPECTAVI_HASH_SEED fixed a seed. */
+void nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int k,
+                       int hash_bit_rate, int num_hash_tables, int num_candidate_neighbours,
+                       NdArray *outidx, NdArray *outdist);
+
+/* Two-view DLT triangulation of npt points.  Replaces reference
+ * src/Spectavi.cpp:38-52 (DltTriangulator::solve, src/DltTriangulator.h:36-65).
+ *   P0,P1: double[3,4]; x,xp: double[npt,3] homogeneous; dst: caller double[npt,4].
+ * dst row = unit-norm right singular vector of the smallest singular value of
+ * the 4x4 DLT matrix; its sign (arbitrary in the reference: Eigen JacobiSVD)
+ * is canonicalised to dst[3] >= 0 (first nonzero component > 0 if dst[3]==0). */
+void dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
+                     const double *xp, double *dst);
+
+/* Reprojection error of the triangulated point, ||hn(P0 X)-hn(x)|| + ||hn(P1 X)-hn(xp)||.
+ * Replaces reference src/Spectavi.cpp:54-68 (src/DltTriangulator.h:67-74).
+ * dst: caller double[npt]. */
+void dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
+                            const double *xp, double *dst);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Host-pointer variants: caller-allocated outputs, int status            */
+/* ------------------------------------------------------------------------ */
+
+/* idx: uint64[yrows,2], dist: int32[yrows,2]. */
+int spv_nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
+                          uint64_t *idx, int32_t *dist);
+
+/* As nn_cascading_hash but with explicit hyperplanes: dict is
+ * float32[n, dim, m] (table-major, then dim, then bit: the fill order of
+ * src/CascadingHashNn.h:92-98).  idx: uint64[yrows,2], dist: float32[yrows,2].
+ * ncand (may be NULL): int32[yrows] number of candidate rows examined (bucket
+ * entries visited; a row reached through several tables counts once per table). */
+int spv_nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int m,
+                          int n, int g, const float *dict, uint64_t *idx, float *dist,
+                          int32_t *ncand);
+
+/* Fill dict[n*dim*m] exactly as the reference's generate_hash_dict would from
+ * std::mt19937(seed) + std::normal_distribution<float>(0,1). */
+int spv_generate_hash_dict(uint32_t seed, int dim, int m, int n, float *dict);
+/* Fix (use_fixed != 0) or release the seed used by nn_cascading_hash. */
+void spv_set_hash_seed(uint32_t seed, int use_fixed);
+
+int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
+                        const double *xp, double *dst);
+int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
+                               const double *xp, double *dst);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Device-pointer variants: everything resident in HBM, async on `stream` */
+/*    (`stream` is a hipStream_t passed as void*; NULL = the null stream).    */
+/*    Buffers must belong to the calling thread's current HIP device.         */
+/* ------------------------------------------------------------------------ */
+
+/* Scratch bytes needed by spv_l1k2_device for this shape. */
+size_t spv_l1k2_workspace_bytes(int xrows, int yrows, int dim);
+/* d_x uint8[xrows,dim], d_y uint8[yrows,dim] (16-byte aligned bases),
+ * d_idx uint64[yrows,2], d_dist int32[yrows,2], d_ws >= workspace bytes. */
+int spv_l1k2_device(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int dim,
+                    uint64_t *d_idx, int32_t *d_dist, void *d_ws, size_t ws_bytes,
+                    void *stream);
+
+/* Scratch bytes needed by spv_cascade_device. */
+size_t spv_cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g);
+/* d_x,d_y float32[rows,dim]; d_dict float32[n,dim,m]; outputs as in section 2
+ * (d_ncand may be NULL). */
+int spv_cascade_device(const float *d_x, const float *d_y, int xrows, int yrows, int dim,
+                       int m, int n, int g, const float *d_dict, uint64_t *d_idx,
+                       float *d_dist, int32_t *d_ncand, void *d_ws, size_t ws_bytes,
+                       void *stream);
+
+/* P0,P1 are HOST pointers (24 doubles, passed by value to the kernel);
+ * d_x,d_xp double[npt,3]; d_dst double[npt,4] (triangulate) / double[npt] (error). */
+int spv_dlt_triangulate_device(const double *P0, const double *P1, long long npt,
+                               const double *d_x, const double *d_xp, double *d_dst,
+                               void *stream);
+int spv_dlt_reprojection_error_device(const double *P0, const double *P1, long long npt,
+                                      const double *d_x, const double *d_xp, double *d_dst,
+                                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPECTAVI_AMD_H */

@@ -1,0 +1,188 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) + independent numpy checks.
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never from spectavi_amd/ (the product path has no
+CPU fallback).  Each C function cites the reference lines it restates in its
+own header (oracle_l1k2.cpp, oracle_cascade.cpp, oracle_dlt.cpp).
+
+The numpy helpers at the bottom are a *second*, independent statement of the
+same results (the same role `brute_force_nn_batched` plays in the reference's
+test/test_feature.py:10-26) used to pin the C oracle itself.
+"""
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+from numpy.ctypeslib import ndpointer
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc only, no GPU)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ct.CDLL(_LIB_PATH)
+        u8 = ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        f32 = ndpointer(np.float32, flags="C_CONTIGUOUS")
+        f64 = ndpointer(np.float64, flags="C_CONTIGUOUS")
+        u64 = ndpointer(np.uint64, flags="C_CONTIGUOUS")
+        i32 = ndpointer(np.int32, flags="C_CONTIGUOUS")
+        i64 = ndpointer(np.int64, flags="C_CONTIGUOUS")
+        L.oracle_nn_bruteforcel1k2.restype = ct.c_int
+        L.oracle_nn_bruteforcel1k2.argtypes = [u8, u8, ct.c_int, ct.c_int, ct.c_int, ct.c_int, u64, i32]
+        L.oracle_l1k2_candidates.restype = ct.c_int
+        L.oracle_l1k2_candidates.argtypes = [u8, u8, ct.c_int, ct.c_int, i64, i32, ct.c_int, u64, i32]
+        L.oracle_nn_cascading_hash.restype = ct.c_int
+        L.oracle_nn_cascading_hash.argtypes = [
+            f32, f32, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, f32, u64, f32,
+            ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+        for name in ("oracle_dlt_triangulate", "oracle_dlt_reprojection_error"):
+            fn = getattr(L, name)
+            fn.restype = None
+            fn.argtypes = [f64, f64, ct.c_int, f64, f64, f64]
+        L.oracle_dlt_cheirality.restype = None
+        L.oracle_dlt_cheirality.argtypes = [f64, f64, ct.c_int, f64, f64, u8]
+        L.oracle_max_threads.restype = ct.c_int
+        _lib = L
+    return _lib
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def nn_bruteforcel1k2(x, y, nthreads=1):
+    """(uint64[N,2], int32[N,2]) -- restates reference src/BruteForceNnL1K2.h:84-145."""
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    xrows, dim = x.shape if x.ndim == 2 else (0, y.shape[1])
+    yrows, ydim = y.shape
+    assert xrows == 0 or dim == ydim
+    idx = np.empty((yrows, 2), np.uint64)
+    dist = np.empty((yrows, 2), np.int32)
+    rc = lib().oracle_nn_bruteforcel1k2(x.reshape(-1, ydim), y, xrows, yrows, ydim, nthreads, idx, dist)
+    if rc != 0:
+        raise ValueError("Input matrix inner dimensions must be 16-byte aligned.")
+    return idx, dist
+
+
+def nn_cascading_hash(x, y, m, n, g, dict_, debug=False):
+    """(uint64[N,2], float32[N,2], ncand int32[N], nset int32[N]) -- restates
+    reference src/CascadingHashNn.h:86-245 with explicit hyperplanes dict_[n,dim,m]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    dict_ = np.ascontiguousarray(dict_, dtype=np.float32)
+    xrows, dim = x.shape
+    yrows = y.shape[0]
+    assert dict_.shape == (n, dim, m)
+    idx = np.empty((yrows, 2), np.uint64)
+    dist = np.empty((yrows, 2), np.float32)
+    ncand = np.zeros(yrows, np.int32)
+    nset = np.zeros(yrows, np.int32)
+    xcodes = np.zeros((n, xrows), np.uint32)
+    ysign = np.zeros((n, yrows), np.uint32)
+    ymask = np.zeros((n, yrows), np.uint32)
+    rc = lib().oracle_nn_cascading_hash(
+        x, y, xrows, yrows, dim, m, n, g, dict_, idx, dist,
+        ncand.ctypes.data, nset.ctypes.data,
+        xcodes.ctypes.data if debug else None,
+        ysign.ctypes.data if debug else None,
+        ymask.ctypes.data if debug else None)
+    if rc != 0:
+        raise ValueError("bad cascade arguments")
+    if debug:
+        return idx, dist, ncand, nset, xcodes, ysign, ymask
+    return idx, dist, ncand, nset
+
+
+def _dlt_args(P0, P1, x, xp):
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    P1 = np.ascontiguousarray(P1, dtype=np.float64)
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+    xp = np.ascontiguousarray(np.atleast_2d(xp), dtype=np.float64)
+    assert P0.shape == (3, 4) and P1.shape == (3, 4)
+    assert x.shape == xp.shape and x.shape[1] == 3
+    return P0, P1, x, xp
+
+
+def dlt_triangulate(P0, P1, x, xp):
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    dst = np.empty((x.shape[0], 4))
+    lib().oracle_dlt_triangulate(P0, P1, x.shape[0], x, xp, dst)
+    return dst
+
+
+def dlt_reprojection_error(P0, P1, x, xp):
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    dst = np.empty((x.shape[0], 1))
+    lib().oracle_dlt_reprojection_error(P0, P1, x.shape[0], x, xp, dst)
+    return dst
+
+
+def dlt_cheirality(P0, P1, x, xp):
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    out = np.empty(x.shape[0], np.uint8)
+    lib().oracle_dlt_cheirality(P0, P1, x.shape[0], x, xp, out)
+    return out.astype(bool)
+
+
+# ----------------------------------------------------------------------------------
+# independent numpy statements (pin the C oracle; small sizes only)
+# ----------------------------------------------------------------------------------
+def numpy_l1_top2(x, y, batch=256):
+    """Exact L1 two smallest (dist, idx) pairs per query row, lexicographic.
+    Distances follow reference test/test_feature.py:10-26 (full |x-y| sum); the
+    tie rule (lower index first) is made explicit with a stable argsort."""
+    x = x.astype(np.int32)
+    y = y.astype(np.int32)
+    n, m = y.shape[0], x.shape[0]
+    idx = np.full((n, 2), np.iinfo(np.uint64).max, np.uint64)
+    dist = np.full((n, 2), np.iinfo(np.int32).max, np.int32)
+    if m == 0:
+        return idx, dist
+    for i in range(0, n, batch):
+        d = np.abs(y[i:i + batch, None, :] - x[None, :, :]).sum(-1)  # [b, m]
+        order = np.argsort(d, axis=1, kind="stable")[:, :2]
+        k = order.shape[1]
+        idx[i:i + batch, :k] = order.astype(np.uint64)
+        dist[i:i + batch, :k] = np.take_along_axis(d, order, axis=1).astype(np.int32)
+    return idx, dist
+
+
+def candidates_from_codes(xcodes, ysign, ymask):
+    """[N, M] bool: k is a candidate of i iff some table j has
+    ((xcode_j[k] ^ ysign_j[i]) & ~ymask_j[i]) == 0."""
+    n = xcodes.shape[0]
+    out = np.zeros((ysign.shape[1], xcodes.shape[1]), bool)
+    for j in range(n):
+        diff = (xcodes[j][None, :] ^ ysign[j][:, None]) & ~ymask[j][:, None]
+        out |= diff == 0
+    return out
+
+
+def numpy_dlt_null_vector(P0, P1, x, xp):
+    """LAPACK SVD null vector of the DLT matrix (reference src/DltTriangulator.h:51-58),
+    sign-canonicalised like the oracle (X[3] >= 0)."""
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    out = np.empty((x.shape[0], 4))
+    for i in range(x.shape[0]):
+        u, v = x[i, 0] / x[i, 2], x[i, 1] / x[i, 2]
+        up, vp = xp[i, 0] / xp[i, 2], xp[i, 1] / xp[i, 2]
+        A = np.stack([u * P0[2] - P0[0], v * P0[2] - P0[1], up * P1[2] - P1[0], vp * P1[2] - P1[1]])
+        X = np.linalg.svd(A)[2][3]
+        nz = X[3] if X[3] != 0 else X[np.flatnonzero(X)[0]]
+        out[i] = -X if nz < 0 else X
+    return out

@@ -1,0 +1,178 @@
+// oracle_dlt.cpp -- CPU restatement of the reference's two-view DLT triangulation.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle_l1k2.cpp header): never imported, linked
+// or called from spectavi_amd/.
+//
+// Follows (read as text, restated, not copied):
+//   reference src/DltTriangulator.h:36-65  solve: hnormalize both observations
+//       (:38-45), A rows u*P[2]-P[0], v*P[2]-P[1] per view (:51-54), X = right
+//       singular vector of the smallest singular value (:56-58), reprojections (:61-62)
+//   reference src/DltTriangulator.h:67-74  reprojection_error: sum of the two
+//       Euclidean pixel distances
+//   reference src/DltTriangulator.h:76-86  cheirality (distance2camera*, not exported
+//       through the C-ABI; provided for the RANSAC-scoring "next" row)
+//   reference src/Spectavi.cpp:38-68        the serial per-point loops
+//
+// The SVD itself lives in Eigen (JacobiSVD, version unpinned by the reference
+// build, absent here).  It is restated as a one-sided (Hestenes) Jacobi
+// iteration in fp64 -- the same operation sequence the HIP kernel executes, with
+// floating-point contraction disabled on both sides -- and pinned two ways in
+// tests/test_oracle.py: (a) the reference's own test properties
+// (test/test_mvg.py:94-125: reprojection error < 1e-3 and X == X0 up to scale on
+// noise-free random cameras), (b) numpy.linalg.svd (LAPACK) null vectors of the
+// same A.  PARITY UNPINNED: the sign of X (arbitrary in Eigen); canonicalised
+// here and in the HIP path to X[3] >= 0.
+
+#include <cmath>
+#include <cstdint>
+
+namespace {
+
+constexpr int kMaxSweeps = 30;
+
+struct Solve {
+  double X[4];
+  double u, v, up, vp;
+};
+
+inline void dlt_solve(const double *P0, const double *P1, const double *x, const double *xp,
+                      Solve &out) {
+  const double u = x[0] / x[2], v = x[1] / x[2];
+  const double up = xp[0] / xp[2], vp = xp[1] / xp[2];
+  double A[4][4], V[4][4];
+  for (int c = 0; c < 4; ++c) {
+    A[0][c] = u * P0[8 + c] - P0[0 + c];
+    A[1][c] = v * P0[8 + c] - P0[4 + c];
+    A[2][c] = up * P1[8 + c] - P1[0 + c];
+    A[3][c] = vp * P1[8 + c] - P1[4 + c];
+  }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
+
+  const double eps = 1e-15;
+  for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 3; ++p) {
+      for (int q = p + 1; q < 4; ++q) {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (int i = 0; i < 4; ++i) {
+          alpha += A[i][p] * A[i][p];
+          beta += A[i][q] * A[i][q];
+          gamma += A[i][p] * A[i][q];
+        }
+        const double lim = eps * std::sqrt(alpha * beta);
+        if (std::fabs(gamma) > lim && gamma != 0.0) {
+          rotated = true;
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double tt = 1.0 / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+          const double tn = zeta < 0.0 ? -tt : tt;
+          const double cs = 1.0 / std::sqrt(1.0 + tn * tn);
+          const double sn = cs * tn;
+          for (int i = 0; i < 4; ++i) {
+            const double ap = A[i][p], aq = A[i][q];
+            A[i][p] = cs * ap - sn * aq;
+            A[i][q] = sn * ap + cs * aq;
+            const double vp_ = V[i][p], vq_ = V[i][q];
+            V[i][p] = cs * vp_ - sn * vq_;
+            V[i][q] = sn * vp_ + cs * vq_;
+          }
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+  double best = 0.0;
+  int kbest = 0;
+  for (int c = 0; c < 4; ++c) {
+    double nn = 0.0;
+    for (int i = 0; i < 4; ++i) nn += A[i][c] * A[i][c];
+    if (c == 0 || nn < best) {
+      best = nn;
+      kbest = c;
+    }
+  }
+  double xv[4];
+  for (int i = 0; i < 4; ++i) xv[i] = V[i][kbest];
+  double nrm = 0.0;
+  for (int i = 0; i < 4; ++i) nrm += xv[i] * xv[i];
+  nrm = std::sqrt(nrm);
+  bool neg;
+  if (xv[3] != 0.0)
+    neg = xv[3] < 0.0;
+  else if (xv[0] != 0.0)
+    neg = xv[0] < 0.0;
+  else if (xv[1] != 0.0)
+    neg = xv[1] < 0.0;
+  else
+    neg = xv[2] < 0.0;
+  const double scale = neg ? -nrm : nrm;
+  for (int i = 0; i < 4; ++i) out.X[i] = xv[i] / scale;
+  out.u = u;
+  out.v = v;
+  out.up = up;
+  out.vp = vp;
+}
+
+inline void reproject(const double *P, const double *X, double *r) {
+  for (int k = 0; k < 3; ++k) {
+    double a = 0.0;
+    for (int c = 0; c < 4; ++c) a += P[4 * k + c] * X[c];
+    r[k] = a;
+  }
+}
+
+inline double det3(const double *P) {
+  // determinant of the left 3x3 block of a row-major 3x4
+  return P[0] * (P[5] * P[10] - P[6] * P[9]) - P[1] * (P[4] * P[10] - P[6] * P[8]) +
+         P[2] * (P[4] * P[9] - P[5] * P[8]);
+}
+
+}  // namespace
+
+extern "C" {
+
+// dst: double[npt,4].  Serial loop, as reference src/Spectavi.cpp:48-51.
+void oracle_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
+                            const double *xp, double *dst) {
+  for (int i = 0; i < npt; ++i) {
+    Solve s;
+    dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
+    for (int k = 0; k < 4; ++k) dst[4 * (size_t)i + k] = s.X[k];
+  }
+}
+
+// dst: double[npt].  As reference src/Spectavi.cpp:64-67.
+void oracle_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
+                                   const double *xp, double *dst) {
+  for (int i = 0; i < npt; ++i) {
+    Solve s;
+    dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
+    double r0[3], r1[3];
+    reproject(P0, s.X, r0);
+    reproject(P1, s.X, r1);
+    const double e0x = r0[0] / r0[2] - s.u, e0y = r0[1] / r0[2] - s.v;
+    const double e1x = r1[0] / r1[2] - s.up, e1y = r1[1] / r1[2] - s.vp;
+    dst[i] = std::sqrt(e0x * e0x + e0y * e0y) + std::sqrt(e1x * e1x + e1y * e1y);
+  }
+}
+
+// infront: uint8[npt], 1 iff the point is in front of both cameras
+// (reference src/DltTriangulator.h:76-86).
+void oracle_dlt_cheirality(const double *P0, const double *P1, int npt, const double *x,
+                           const double *xp, uint8_t *infront) {
+  const double s0 = det3(P0) < 0 ? -1.0 : 1.0, s1 = det3(P1) < 0 ? -1.0 : 1.0;
+  const double n0 = P0[2] * P0[2] + P0[6] * P0[6] + P0[10] * P0[10];
+  const double n1 = P1[2] * P1[2] + P1[6] * P1[6] + P1[10] * P1[10];
+  for (int i = 0; i < npt; ++i) {
+    Solve s;
+    dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
+    double r0[3], r1[3];
+    reproject(P0, s.X, r0);
+    reproject(P1, s.X, r1);
+    const double dc0 = s0 / n0 * r0[2] / s.X[3];
+    const double dc1 = s1 / n1 * r1[2] / s.X[3];
+    infront[i] = (dc0 > 0 && dc1 > 0) ? 1 : 0;
+  }
+}
+
+}  // extern "C"

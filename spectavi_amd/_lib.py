@@ -1,0 +1,66 @@
+"""Loader for libspectavi.so (gfx950 build).
+
+Counterpart of reference spectavi/__libspectavi.py:1-9: the shared library sits
+next to the package and is opened with ctypes.  There is no CPU fallback: a
+missing library raises ImportError here, and a missing GPU surfaces as
+SpectaviError from the first call.
+"""
+import ctypes as ct
+import os
+
+_PKG_DIR = os.path.dirname(os.path.realpath(__file__))
+lib_path = os.path.join(_PKG_DIR, "libspectavi.so")
+
+if not os.path.exists(lib_path):
+    raise ImportError(
+        "libspectavi.so (HIP/gfx950) is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C spectavi_amd/csrc`.  spectavi_amd has no CPU fallback.")
+
+clib = ct.cdll.LoadLibrary(lib_path)
+
+SPV_OK, SPV_ERR_INVALID, SPV_ERR_HIP, SPV_ERR_NOMEM = 0, 1, 2, 3
+
+clib.spv_last_status.restype = ct.c_int
+clib.spv_last_status.argtypes = []
+clib.spv_last_error.restype = ct.c_char_p
+clib.spv_last_error.argtypes = []
+clib.spv_version.restype = ct.c_char_p
+clib.spv_version.argtypes = []
+clib.spv_device_count.restype = ct.c_int
+clib.spv_device_count.argtypes = []
+clib.spv_set_device.restype = ct.c_int
+clib.spv_set_device.argtypes = [ct.c_int]
+clib.spv_set_hash_seed.restype = None
+clib.spv_set_hash_seed.argtypes = [ct.c_uint32, ct.c_int]
+
+
+class SpectaviError(RuntimeError):
+    """Raised when a libspectavi entry point reports a non-zero status."""
+
+    def __init__(self, status, message):
+        super().__init__("libspectavi status %d: %s" % (status, message))
+        self.status = status
+
+
+def check(status=None):
+    """Raise SpectaviError if `status` (or the thread's last status) is non-zero."""
+    if status is None:
+        status = clib.spv_last_status()
+    if status != SPV_OK:
+        raise SpectaviError(status, (clib.spv_last_error() or b"").decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(clib.spv_device_count())
+
+
+def set_device(device):
+    check(clib.spv_set_device(int(device)))
+
+
+def set_hash_seed(seed=None):
+    """Fix the hyperplane seed of nn_cascading_hash (None: back to std::random_device)."""
+    if seed is None:
+        clib.spv_set_hash_seed(0, 0)
+    else:
+        clib.spv_set_hash_seed(int(seed) & 0xFFFFFFFF, 1)

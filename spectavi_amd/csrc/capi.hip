@@ -1,0 +1,463 @@
+// capi.hip -- extern "C" surface of libspectavi.so (declared in include/spectavi_amd.h).
+//
+// Host-pointer entry points own the H2D/D2H traffic and scratch allocation and
+// call the same device-pointer runners (l1k2_run / cascade_run / dlt_run) the
+// section-3 symbols expose.  No compute happens on the host and there is no
+// CPU fallback: every path ends in a HIP kernel launch or in an error status.
+
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <random>
+#include <vector>
+
+namespace spv {
+
+namespace {
+thread_local int g_status = SPV_OK;
+thread_local char g_message[512] = "";
+
+std::mutex g_cfg_mutex;
+int g_device = -1;  // -1: not chosen yet
+bool g_seed_fixed = false;
+uint32_t g_seed = 0;
+}  // namespace
+
+int set_error(int status, const char *fmt, ...) {
+  g_status = status;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_message, sizeof(g_message), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+void clear_error() {
+  g_status = SPV_OK;
+  g_message[0] = '\0';
+}
+
+// ---- optional kernel timing ----------------------------------------------------------
+namespace {
+std::mutex g_prof_mutex;
+std::atomic<bool> g_prof_on{false};
+std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> g_prof;
+}  // namespace
+
+ProfScope::ProfScope(const char *name, hipStream_t stream) : name_(name), stream_(stream) {
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  if (hipEventCreate(&start_) != hipSuccess) {
+    start_ = nullptr;
+    return;
+  }
+  (void)hipEventRecord(start_, stream_);
+}
+
+ProfScope::~ProfScope() {
+  if (!start_) return;
+  hipEvent_t stop = nullptr;
+  if (hipEventCreate(&stop) != hipSuccess) {
+    (void)hipEventDestroy(start_);
+    return;
+  }
+  (void)hipEventRecord(stop, stream_);
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
+  g_prof[name_].emplace_back(start_, stop);
+}
+
+int ensure_device() {
+  int dev;
+  {
+    std::lock_guard<std::mutex> lk(g_cfg_mutex);
+    if (g_device < 0) {
+      const char *e = getenv("SPECTAVI_DEVICE");
+      g_device = (e && *e) ? atoi(e) : 0;
+    }
+    dev = g_device;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return set_error(SPV_ERR_HIP, "no HIP device available (%s); libspectavi has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (dev >= count) return set_error(SPV_ERR_HIP, "SPECTAVI_DEVICE=%d but only %d devices", dev, count);
+  SPV_HIP_CHECK(hipSetDevice(dev));
+  return SPV_OK;
+}
+
+namespace {
+
+// RAII device buffer for the host-pointer paths.
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return set_error(SPV_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return SPV_OK;
+  }
+  template <typename T>
+  T *as() {
+    return static_cast<T *>(p);
+  }
+};
+
+#define SPV_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != SPV_OK) return _s; \
+  } while (0)
+
+int host_l1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim, uint64_t *idx,
+              int32_t *dist) {
+  if (xrows < 0 || yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  if (dim <= 0 || dim % 16 != 0)
+    return set_error(SPV_ERR_INVALID,
+                     "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
+  if (yrows == 0) return SPV_OK;
+  if (!y || !idx || !dist || (xrows > 0 && !x)) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  const size_t xb = (size_t)xrows * dim, yb = (size_t)yrows * dim;
+  const size_t wsb = spv_l1k2_workspace_bytes(xrows, yrows, dim);
+  DevBuf dx, dy, di, dd, ws;
+  SPV_TRY(dx.alloc(xb));
+  SPV_TRY(dy.alloc(yb));
+  SPV_TRY(di.alloc((size_t)yrows * 2 * sizeof(uint64_t)));
+  SPV_TRY(dd.alloc((size_t)yrows * 2 * sizeof(int32_t)));
+  SPV_TRY(ws.alloc(wsb));
+  hipStream_t st = nullptr;
+  if (xb) SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, xb, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dy.p, y, yb, hipMemcpyHostToDevice, st));
+  SPV_TRY(l1k2_run(dx.as<uint8_t>(), dy.as<uint8_t>(), xrows, yrows, dim, di.as<uint64_t>(),
+                   dd.as<int32_t>(), ws.p, wsb, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(idx, di.p, (size_t)yrows * 2 * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dist, dd.p, (size_t)yrows * 2 * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
+int check_cascade_args(int xrows, int yrows, int dim, int m, int n, int g) {
+  if (xrows < 0 || yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  if (dim <= 0 || dim % 16 != 0)
+    return set_error(SPV_ERR_INVALID,
+                     "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
+  if (m < 1 || m > 31) return set_error(SPV_ERR_INVALID, "hash_bit_rate m=%d must be in [1,31]", m);
+  if (n < 1) return set_error(SPV_ERR_INVALID, "num_hash_tables n=%d must be >= 1", n);
+  if (g < 0 || g > m || g > 16)
+    return set_error(SPV_ERR_INVALID, "num_candidate_neighbours g=%d must be in [0,min(m,16)]", g);
+  return SPV_OK;
+}
+
+int host_cascade(const float *x, const float *y, int xrows, int yrows, int dim, int m, int n,
+                 int g, const float *dict, uint64_t *idx, float *dist, int32_t *ncand) {
+  SPV_TRY(check_cascade_args(xrows, yrows, dim, m, n, g));
+  if (yrows == 0) return SPV_OK;
+  if (!y || !idx || !dist || !dict || (xrows > 0 && !x))
+    return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  const size_t xb = (size_t)xrows * dim * sizeof(float), yb = (size_t)yrows * dim * sizeof(float);
+  const size_t db = (size_t)n * dim * m * sizeof(float);
+  const size_t wsb = cascade_workspace_bytes(xrows, yrows, dim, m, n, g);
+  DevBuf dx, dy, dd, di, dds, dn, ws;
+  SPV_TRY(dx.alloc(xb));
+  SPV_TRY(dy.alloc(yb));
+  SPV_TRY(dd.alloc(db));
+  SPV_TRY(di.alloc((size_t)yrows * 2 * sizeof(uint64_t)));
+  SPV_TRY(dds.alloc((size_t)yrows * 2 * sizeof(float)));
+  SPV_TRY(dn.alloc((size_t)yrows * sizeof(int32_t)));
+  SPV_TRY(ws.alloc(wsb));
+  hipStream_t st = nullptr;
+  if (xb) SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, xb, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dy.p, y, yb, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dd.p, dict, db, hipMemcpyHostToDevice, st));
+  SPV_TRY(cascade_run(dx.as<float>(), dy.as<float>(), xrows, yrows, dim, m, n, g, dd.as<float>(),
+                      di.as<uint64_t>(), dds.as<float>(), dn.as<int32_t>(), ws.p, wsb, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(idx, di.p, (size_t)yrows * 2 * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dist, dds.p, (size_t)yrows * 2 * sizeof(float),
+                               hipMemcpyDeviceToHost, st));
+  if (ncand)
+    SPV_HIP_CHECK(hipMemcpyAsync(ncand, dn.p, (size_t)yrows * sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
+int host_dlt(const double *P0, const double *P1, int npt, const double *x, const double *xp,
+             double *dst, bool want_error) {
+  if (npt < 0) return set_error(SPV_ERR_INVALID, "negative point count");
+  if (npt == 0) return SPV_OK;
+  if (!P0 || !P1 || !x || !xp || !dst) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  const size_t ib = (size_t)npt * 3 * sizeof(double);
+  const size_t ob = (size_t)npt * (want_error ? 1 : 4) * sizeof(double);
+  DevBuf dx, dxp, dd;
+  SPV_TRY(dx.alloc(ib));
+  SPV_TRY(dxp.alloc(ib));
+  SPV_TRY(dd.alloc(ob));
+  hipStream_t st = nullptr;
+  SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, xp, ib, hipMemcpyHostToDevice, st));
+  SPV_TRY(dlt_run(P0, P1, npt, dx.as<double>(), dxp.as<double>(), dd.as<double>(), want_error, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dst, dd.p, ob, hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
+// Hyperplanes as the reference draws them (src/CascadingHashNn.h:86-100):
+// one std::mt19937 stream, std::normal_distribution<float>(0,1), table-major,
+// then dim (i), then bit (j).
+void fill_hash_dict(uint32_t seed, int dim, int m, int n, float *dict) {
+  std::mt19937 gen(seed);
+  std::normal_distribution<float> normal(0.f, 1.f);
+  const size_t total = (size_t)n * dim * m;
+  for (size_t e = 0; e < total; ++e) dict[e] = normal(gen);
+}
+
+int alloc_out(NdArray *arr, size_t rows, size_t cols, int itemsize) {
+  if (!arr) return set_error(SPV_ERR_INVALID, "null NdArray");
+  if (arr->m_itemsize != itemsize)
+    return set_error(SPV_ERR_INVALID, "NdArray itemsize %d, expected %d", arr->m_itemsize, itemsize);
+  ndarray_set_size(arr, rows, cols);
+  if (ndarray_alloc(arr) != 0) return set_error(SPV_ERR_NOMEM, "ndarray_alloc failed");
+  return SPV_OK;
+}
+
+}  // namespace
+}  // namespace spv
+
+using namespace spv;
+
+extern "C" {
+
+// ---- NdArray ------------------------------------------------------------------------
+void ndarray_set_size(NdArray *arr, size_t d0, size_t d1) {
+  arr->m_ndim = 2;
+  arr->m_shape[0] = d0;
+  arr->m_shape[1] = d1;
+  arr->m_shape[2] = arr->m_shape[3] = 1;
+}
+void ndarray_set_size3(NdArray *arr, size_t d0, size_t d1, size_t d2) {
+  arr->m_ndim = 3;
+  arr->m_shape[0] = d0;
+  arr->m_shape[1] = d1;
+  arr->m_shape[2] = d2;
+  arr->m_shape[3] = 1;
+}
+int ndarray_alloc(NdArray *arr) {
+  size_t n = (size_t)(arr->m_itemsize > 0 ? arr->m_itemsize : 1);
+  for (int i = 0; i < arr->m_ndim; ++i) n *= arr->m_shape[i];
+  if (arr->m_data) free(arr->m_data);
+  arr->m_data = malloc(n ? n : 1);
+  return arr->m_data ? 0 : 1;
+}
+void ndarray_free(NdArray *arr) {
+  if (arr && arr->m_data) {
+    free(arr->m_data);
+    arr->m_data = nullptr;
+  }
+}
+
+// ---- status -------------------------------------------------------------------------
+int spv_last_status(void) { return g_status; }
+const char *spv_last_error(void) { return g_message; }
+const char *spv_version(void) { return "spectavi_amd 0.1 (gfx950)"; }
+int spv_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+int spv_set_device(int device) {
+  clear_error();
+  if (device < 0) return set_error(SPV_ERR_INVALID, "device %d", device);
+  std::lock_guard<std::mutex> lk(g_cfg_mutex);
+  g_device = device;
+  return SPV_OK;
+}
+
+void spv_profile_enable(int on) { g_prof_on.store(on != 0); }
+
+void spv_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
+  for (auto &kv : g_prof)
+    for (auto &ev : kv.second) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+  g_prof.clear();
+}
+
+int spv_profile_read(const char *kernel, long long *launches, double *total_ms) {
+  clear_error();
+  if (!kernel || !launches || !total_ms) return set_error(SPV_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
+  *launches = 0;
+  *total_ms = 0.0;
+  auto it = g_prof.find(kernel);
+  if (it == g_prof.end()) return SPV_OK;
+  for (auto &ev : it->second) {
+    SPV_HIP_CHECK(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    SPV_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+    *total_ms += ms;
+    *launches += 1;
+  }
+  return SPV_OK;
+}
+
+// ---- reference-compatible symbols ---------------------------------------------------
+void nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
+                       int nthreads, NdArray *outidx, NdArray *outdist) {
+  (void)nthreads;  // OpenMP team size in the reference; the GPU path has no use for it
+  clear_error();
+  if (yrows < 0) {
+    set_error(SPV_ERR_INVALID, "negative row count");
+    return;
+  }
+  if (alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)) != SPV_OK) return;
+  if (alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(int)) != SPV_OK) return;
+  host_l1k2(x, y, xrows, yrows, dim, static_cast<uint64_t *>(outidx->m_data),
+            static_cast<int32_t *>(outdist->m_data));
+}
+
+void nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int k,
+                       int hash_bit_rate, int num_hash_tables, int num_candidate_neighbours,
+                       NdArray *outidx, NdArray *outdist) {
+  clear_error();
+  if (k != 2) {
+    set_error(SPV_ERR_INVALID, "k=%d: only k=2 is defined (reference writes exactly two columns)", k);
+    return;
+  }
+  if (check_cascade_args(xrows, yrows, dim, hash_bit_rate, num_hash_tables,
+                         num_candidate_neighbours) != SPV_OK)
+    return;
+  if (alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)) != SPV_OK) return;
+  if (alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(float)) != SPV_OK) return;
+  uint32_t seed;
+  {
+    std::lock_guard<std::mutex> lk(g_cfg_mutex);
+    const char *e = getenv("SPECTAVI_HASH_SEED");
+    if (g_seed_fixed)
+      seed = g_seed;
+    else if (e && *e)
+      seed = (uint32_t)strtoul(e, nullptr, 0);
+    else
+      seed = std::random_device{}();  // as reference src/CascadingHashNn.h:87-88
+  }
+  std::vector<float> dict((size_t)num_hash_tables * dim * hash_bit_rate);
+  fill_hash_dict(seed, dim, hash_bit_rate, num_hash_tables, dict.data());
+  host_cascade(x, y, xrows, yrows, dim, hash_bit_rate, num_hash_tables, num_candidate_neighbours,
+               dict.data(), static_cast<uint64_t *>(outidx->m_data),
+               static_cast<float *>(outdist->m_data), nullptr);
+}
+
+void dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
+                     const double *xp, double *dst) {
+  clear_error();
+  host_dlt(P0, P1, npt, x, xp, dst, false);
+}
+
+void dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
+                            const double *xp, double *dst) {
+  clear_error();
+  host_dlt(P0, P1, npt, x, xp, dst, true);
+}
+
+// ---- host-pointer status variants ---------------------------------------------------
+int spv_nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
+                          uint64_t *idx, int32_t *dist) {
+  clear_error();
+  return host_l1k2(x, y, xrows, yrows, dim, idx, dist);
+}
+
+int spv_nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int m,
+                          int n, int g, const float *dict, uint64_t *idx, float *dist,
+                          int32_t *ncand) {
+  clear_error();
+  return host_cascade(x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand);
+}
+
+int spv_generate_hash_dict(uint32_t seed, int dim, int m, int n, float *dict) {
+  clear_error();
+  if (dim <= 0 || m <= 0 || n <= 0 || !dict) return set_error(SPV_ERR_INVALID, "bad dict shape");
+  fill_hash_dict(seed, dim, m, n, dict);
+  return SPV_OK;
+}
+
+void spv_set_hash_seed(uint32_t seed, int use_fixed) {
+  std::lock_guard<std::mutex> lk(g_cfg_mutex);
+  g_seed = seed;
+  g_seed_fixed = use_fixed != 0;
+}
+
+int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
+                        const double *xp, double *dst) {
+  clear_error();
+  return host_dlt(P0, P1, npt, x, xp, dst, false);
+}
+int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
+                               const double *xp, double *dst) {
+  clear_error();
+  return host_dlt(P0, P1, npt, x, xp, dst, true);
+}
+
+// ---- device-pointer variants --------------------------------------------------------
+size_t spv_l1k2_workspace_bytes(int xrows, int yrows, int dim) {
+  if (dim <= 0 || dim % 16 != 0 || dim > 256 || xrows < 0 || yrows < 0) return 0;
+  return l1k2_plan(xrows, yrows, dim).total_bytes;
+}
+
+int spv_l1k2_device(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int dim,
+                    uint64_t *d_idx, int32_t *d_dist, void *d_ws, size_t ws_bytes, void *stream) {
+  clear_error();
+  return l1k2_run(d_x, d_y, xrows, yrows, dim, d_idx, d_dist, d_ws, ws_bytes,
+                  static_cast<hipStream_t>(stream));
+}
+
+size_t spv_cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g) {
+  if (dim <= 0 || dim % 16 != 0 || m < 1 || m > 31 || n < 1 || g < 0 || g > m || xrows < 0 ||
+      yrows < 0)
+    return 0;
+  return cascade_workspace_bytes(xrows, yrows, dim, m, n, g);
+}
+
+int spv_cascade_device(const float *d_x, const float *d_y, int xrows, int yrows, int dim, int m,
+                       int n, int g, const float *d_dict, uint64_t *d_idx, float *d_dist,
+                       int32_t *d_ncand, void *d_ws, size_t ws_bytes, void *stream) {
+  clear_error();
+  int s = check_cascade_args(xrows, yrows, dim, m, n, g);
+  if (s != SPV_OK) return s;
+  return cascade_run(d_x, d_y, xrows, yrows, dim, m, n, g, d_dict, d_idx, d_dist, d_ncand, d_ws,
+                     ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int spv_dlt_triangulate_device(const double *P0, const double *P1, long long npt,
+                               const double *d_x, const double *d_xp, double *d_dst,
+                               void *stream) {
+  clear_error();
+  return dlt_run(P0, P1, npt, d_x, d_xp, d_dst, false, static_cast<hipStream_t>(stream));
+}
+int spv_dlt_reprojection_error_device(const double *P0, const double *P1, long long npt,
+                                      const double *d_x, const double *d_xp, double *d_dst,
+                                      void *stream) {
+  clear_error();
+  return dlt_run(P0, P1, npt, d_x, d_xp, d_dst, true, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,532 @@
+// cascade.hip -- cascade-hash candidate prefilter + exact L1 refine for gfx950 (MI355X).
+//
+// Replaces reference CascadingHashNn (src/CascadingHashNn.h:86-245) behind
+// nn_cascading_hash (src/Spectavi.cpp:321-336).  The reference builds
+// unordered_map<code, list<idx>> buckets on the host, and per query unions the
+// buckets of 2^g multi-probe codes per table into an unordered_set that feeds
+// the L1 brute force as a candidate filter.  Here everything is flat arrays in
+// HBM and seven kernels:
+//
+//   1 repack_dict     dict[n][dim][m] -> dictp[n][dim][MC], MC = roundup(m,8), zero padded
+//   2 project<false>  database rows: n*m random-hyperplane projections as a
+//                     dim-ordered fp32 FMA chain (the oracle runs the identical
+//                     chain, so sign bits match bit for bit), sign-packed codes
+//                     (bit b set iff proj >= 0, src/CascadingHashNn.h:102-111) and
+//                     the uint8 refine image  u8 = (int(trunc v) + 128) & 255
+//                     (src/CascadingHashNn.h:236-239)
+//   3 project<true>   query rows: sign code + mask of the g least-confident bits
+//                     (smallest (|proj|, bit) pairs, src/CascadingHashNn.h:150-160)
+//                     + uint8 image
+//   4 bucket_count / 5 bucket_scan / 6 bucket_fill   counting sort of database
+//                     indices by bucket = code & (2^HB - 1), per table
+//   7 probe_refine    one wave per query: 2^g probe codes per table
+//                     (src/CascadingHashNn.h:170-179) -> bucket ranges -> candidate
+//                     list in LDS -> 8 lanes gather one 128-byte candidate row each
+//                     (8 rows per wave instruction), v_sad_u8 + DPP reduce, running
+//                     two smallest (dist, idx) keys per lane group, then a
+//                     wavefront-shuffle argmin-2 merge over the 8 groups.
+//
+// Candidate semantics (closed form of filter_potential_neighbours, :208-227):
+// database row k is a candidate of query i iff for some table j
+//   ((code_j(x_k) ^ sign_j(y_i)) & ~mask_j(y_i)) == 0.
+// The reference visits the candidate set in unordered_set order, so its
+// tie-break on equal distance is unspecified; here the result is the two
+// smallest (dist, idx) pairs of the candidate set, lexicographic.
+
+#include "common.h"
+
+#include <algorithm>
+
+namespace spv {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBucketBits = 22;
+constexpr int kListCap = 512;  // candidate indices staged in LDS per wave
+constexpr uint64_t kNone64 = ~0ull;
+
+inline int bucket_bits(int m) { return std::min(m, kMaxBucketBits); }
+
+// ---------------------------------------------------------------------------------
+// 1. dictionary repack
+// ---------------------------------------------------------------------------------
+__global__ void repack_dict_kernel(const float *__restrict__ dict, float *__restrict__ dictp, int n,
+                                   int dim, int m, int mc) {
+  const int total = n * dim * mc;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int b = e % mc;
+    const int ji = e / mc;  // j*dim + i
+    dictp[e] = b < m ? dict[(size_t)ji * m + b] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 2/3. projections, codes, uint8 image.  One lane per row; the row is read 16
+// floats at a time (lane-private, 64-byte pieces), the MC accumulators of one
+// table live in registers, dictionary values arrive as wave-uniform scalars.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2u8(float v) {
+  return (uint32_t)((int)v + 128) & 0xFFu;  // trunc toward zero, wrap mod 256
+}
+
+template <int MC, bool IS_QUERY, int GMAX>
+__global__ __launch_bounds__(kThreads) void project_kernel(
+    const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
+    const float *__restrict__ dictp,     // [n][dim][MC]
+    uint32_t *__restrict__ codes,        // [n][nrows] sign codes
+    uint32_t *__restrict__ masks,        // [n][nrows] (queries only)
+    uint8_t *__restrict__ u8img) {       // [nrows][dim]
+  const int r = blockIdx.x * kThreads + threadIdx.x;
+  const int rr = min(r, nrows - 1);
+  const float4 *src = reinterpret_cast<const float4 *>(rows + (size_t)rr * dim);
+  for (int j = 0; j < n; ++j) {
+    float acc[MC];
+#pragma unroll
+    for (int b = 0; b < MC; ++b) acc[b] = 0.f;
+    const float *dj = dictp + (size_t)j * dim * MC;
+    for (int i0 = 0; i0 < dim; i0 += 16) {
+      float xv[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 v = src[i0 / 4 + c];
+        xv[4 * c + 0] = v.x;
+        xv[4 * c + 1] = v.y;
+        xv[4 * c + 2] = v.z;
+        xv[4 * c + 3] = v.w;
+      }
+      if (j == 0 && r < nrows) {
+        uint4 pk;
+        pk.x = f2u8(xv[0]) | (f2u8(xv[1]) << 8) | (f2u8(xv[2]) << 16) | (f2u8(xv[3]) << 24);
+        pk.y = f2u8(xv[4]) | (f2u8(xv[5]) << 8) | (f2u8(xv[6]) << 16) | (f2u8(xv[7]) << 24);
+        pk.z = f2u8(xv[8]) | (f2u8(xv[9]) << 8) | (f2u8(xv[10]) << 16) | (f2u8(xv[11]) << 24);
+        pk.w = f2u8(xv[12]) | (f2u8(xv[13]) << 8) | (f2u8(xv[14]) << 16) | (f2u8(xv[15]) << 24);
+        *reinterpret_cast<uint4 *>(u8img + (size_t)r * dim + i0) = pk;
+      }
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        const float *dr = dj + (size_t)(i0 + ii) * MC;  // wave-uniform -> scalar loads
+#pragma unroll
+        for (int b = 0; b < MC; ++b) acc[b] = __builtin_fmaf(xv[ii], dr[b], acc[b]);
+      }
+    }
+    uint32_t code = 0;
+#pragma unroll
+    for (int b = 0; b < MC; ++b)
+      if (b < m && acc[b] >= 0.f) code |= 1u << b;
+    if (r < nrows) codes[(size_t)j * nrows + r] = code;
+    if (IS_QUERY) {
+      // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
+      // order so a strict < keeps the lower bit on equal magnitude
+      float best[GMAX];
+      int bbit[GMAX];
+#pragma unroll
+      for (int t = 0; t < GMAX; ++t) {
+        best[t] = __builtin_inff();
+        bbit[t] = -1;
+      }
+#pragma unroll
+      for (int b = 0; b < MC; ++b) {
+        if (b < m) {
+          float v = fabsf(acc[b]);
+          int vb = b;
+#pragma unroll
+          for (int t = 0; t < GMAX; ++t) {
+            if (t < g) {
+              const bool lt = v < best[t];
+              const float tv = best[t];
+              const int tb = bbit[t];
+              best[t] = lt ? v : tv;
+              bbit[t] = lt ? vb : tb;
+              v = lt ? tv : v;
+              vb = lt ? tb : vb;
+            }
+          }
+        }
+      }
+      uint32_t mask = 0;
+#pragma unroll
+      for (int t = 0; t < GMAX; ++t)
+        if (t < g && bbit[t] >= 0) mask |= 1u << bbit[t];
+      if (r < nrows) masks[(size_t)j * nrows + r] = mask;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 4-6. counting sort of database indices by bucket, per table
+// ---------------------------------------------------------------------------------
+__global__ void bucket_count_kernel(const uint32_t *__restrict__ codes, int M, int n,
+                                    uint32_t hbmask, int nb, uint32_t *__restrict__ counts) {
+  const size_t total = (size_t)n * M;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e / M);
+    atomicAdd(&counts[(size_t)j * (nb + 1) + (codes[e] & hbmask)], 1u);
+  }
+}
+
+// Exclusive scan of counts[j][0..nb] in place (one 1024-thread block per table);
+// cursor[j][b] receives a copy of the start offsets for the fill pass.
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict__ counts,
+                                                           uint32_t *__restrict__ cursor, int nb) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  uint32_t *c = counts + (size_t)blockIdx.x * (nb + 1);
+  uint32_t *cu = cursor + (size_t)blockIdx.x * (nb + 1);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base <= nb; base += 1024) {
+    const int e = base + t;
+    const uint32_t v = e <= nb ? c[e] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    const uint32_t excl = carry + woff + incl - v;
+    if (e <= nb) {
+      c[e] = excl;
+      cu[e] = excl;
+    }
+    __syncthreads();
+    if (t == 1023) carry = excl + v;
+    __syncthreads();
+  }
+}
+
+__global__ void bucket_fill_kernel(const uint32_t *__restrict__ codes, int M, int n,
+                                   uint32_t hbmask, int nb, uint32_t *__restrict__ cursor,
+                                   uint32_t *__restrict__ order) {
+  const size_t total = (size_t)n * M;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e / M);
+    const uint32_t idx = (uint32_t)(e - (size_t)j * M);
+    const uint32_t pos = atomicAdd(&cursor[(size_t)j * (nb + 1) + (codes[e] & hbmask)], 1u);
+    order[(size_t)j * M + pos] = idx;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 7. probe + gather + refine, one wave per query
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_sad_u8(a, b, c);
+}
+
+// sum over the 8 lanes of an aligned lane group (DPP: half-mirror, xor 1, xor 2)
+__device__ __forceinline__ uint32_t group8_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /*row_half_mirror*/, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true);
+  return v;
+}
+
+__device__ __forceinline__ void top2_insert_distinct(uint64_t &k1, uint64_t &k2, uint64_t k) {
+  if (k == k1 || k == k2) return;  // same database row reached through another table
+  if (k < k1) {
+    k2 = k1;
+    k1 = k;
+  } else if (k < k2) {
+    k2 = k;
+  }
+}
+
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
+  const uint32_t lo = __shfl_xor((uint32_t)v, mask, 64);
+  const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// two smallest DISTINCT keys of {a1,a2,b1,b2}
+__device__ __forceinline__ void merge_distinct(uint64_t &a1, uint64_t &a2, uint64_t b1, uint64_t b2) {
+  const uint64_t lo = a1 < b1 ? a1 : b1;
+  uint64_t second = kNone64;
+  if (a1 > lo && a1 < second) second = a1;
+  if (a2 > lo && a2 < second) second = a2;
+  if (b1 > lo && b1 < second) second = b1;
+  if (b2 > lo && b2 < second) second = b2;
+  a1 = lo;
+  a2 = second;
+}
+
+// Spread the low bits of v over the set bits of mask (software pdep).
+__device__ __forceinline__ uint32_t deposit_bits(uint32_t v, uint32_t mask) {
+  uint32_t out = 0;
+  while (mask) {
+    const uint32_t low = mask & (0u - mask);
+    if (v & 1u) out |= low;
+    v >>= 1;
+    mask ^= low;
+  }
+  return out;
+}
+
+template <int CPL>  // 16-byte chunks of the row per lane of an 8-lane group (dim <= 128*CPL)
+__global__ __launch_bounds__(kThreads) void probe_refine_kernel(
+    const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int m,
+    int n, int g, int hb, const uint32_t *__restrict__ xcodes, const uint32_t *__restrict__ ysign,
+    const uint32_t *__restrict__ ymask, const uint32_t *__restrict__ bstart,
+    const uint32_t *__restrict__ order, uint64_t *__restrict__ out_idx,
+    float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
+  __shared__ uint32_t lists[kThreads / 64][kListCap];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int query = blockIdx.x * (kThreads / 64) + wave;
+  if (query >= N) return;  // whole wave exits together
+  uint32_t *list = lists[wave];
+  const int sub = lane & 7;    // chunk owner inside the 8-lane group
+  const int grp = lane >> 3;   // candidate slot 0..7
+  const int nchunk = dim / 16;
+  const uint32_t nb = 1u << hb;
+  const uint32_t hbmask = nb - 1;
+  const bool check_code = m > hb;
+
+  // this lane's share of the query row
+  uint4 qv[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = sub + 8 * c;
+    qv[c] = ch < nchunk ? *reinterpret_cast<const uint4 *>(uy + (size_t)query * dim + 16 * ch)
+                        : make_uint4(0, 0, 0, 0);
+  }
+
+  uint64_t k1 = kNone64, k2 = kNone64;
+  int visited = 0;
+
+  auto refine = [&](int count) {
+    // `count` candidate indices in list[0..count): 8 per round, one per lane group
+    for (int c0 = 0; c0 < count; c0 += 8) {
+      const int ci = c0 + grp;
+      const bool live = ci < count;
+      const uint32_t cand = list[live ? ci : 0];
+      uint32_t d = 0;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = sub + 8 * c;
+        if (ch < nchunk) {
+          const uint4 xv = *reinterpret_cast<const uint4 *>(ux + (size_t)cand * dim + 16 * ch);
+          d = sad_u8(qv[c].x, xv.x, d);
+          d = sad_u8(qv[c].y, xv.y, d);
+          d = sad_u8(qv[c].z, xv.z, d);
+          d = sad_u8(qv[c].w, xv.w, d);
+        }
+      }
+      d = group8_sum(d);
+      if (live) top2_insert_distinct(k1, k2, ((uint64_t)d << 32) | cand);
+    }
+  };
+
+  const int nvar = 1 << g;
+  const int nprobe = n * nvar;
+  for (int p0 = 0; p0 < nprobe; p0 += 64) {
+    // one probe per lane: bucket range
+    const int p = p0 + lane;
+    uint32_t s = 0, len = 0, pcode = 0;
+    int tj = 0;
+    if (p < nprobe) {
+      tj = p / nvar;
+      const uint32_t var = (uint32_t)(p % nvar);
+      const uint32_t sg = ysign[(size_t)tj * N + query];
+      const uint32_t mk = ymask[(size_t)tj * N + query];
+      pcode = (sg & ~mk) | deposit_bits(var, mk);
+      const uint32_t *bs = bstart + (size_t)tj * (nb + 1) + (pcode & hbmask);
+      s = bs[0];
+      len = bs[1] - s;
+    }
+    // wave-wide totals
+    uint32_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (!check_code && total <= (uint32_t)kListCap) {
+      // fast path: every lane copies its own bucket into the shared list
+      uint32_t dst = incl - len;
+      const uint32_t *src = order + (size_t)tj * M + s;
+      for (uint32_t i = 0; i < len; ++i) list[dst + i] = src[i];
+      __builtin_amdgcn_wave_barrier();
+      refine((int)total);
+      visited += (int)total;
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // general path: buckets one at a time, 64 entries per step, optional full-code check
+      const int np = min(64, nprobe - p0);
+      for (int pp = 0; pp < np; ++pp) {
+        const uint32_t ps = __shfl(s, pp, 64);
+        const uint32_t pl = __shfl(len, pp, 64);
+        const uint32_t pc = __shfl(pcode, pp, 64);
+        const int pj = __shfl(tj, pp, 64);
+        for (uint32_t off = 0; off < pl; off += 64) {
+          const uint32_t e = off + lane;
+          bool keep = e < pl;
+          uint32_t cand = 0;
+          if (keep) {
+            cand = order[(size_t)pj * M + ps + e];
+            if (check_code) keep = xcodes[(size_t)pj * M + cand] == pc;
+          }
+          const unsigned long long bal = __ballot(keep);
+          const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+          if (keep) list[pos] = cand;
+          const int cnt = __popcll(bal);
+          __builtin_amdgcn_wave_barrier();
+          refine(cnt);
+          visited += cnt;
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+
+  // argmin-2 butterfly over the 8 lane groups (keys are uniform inside a group)
+#pragma unroll
+  for (int msk = 8; msk < 64; msk <<= 1) {
+    const uint64_t b1 = shfl_xor64(k1, msk);
+    const uint64_t b2 = shfl_xor64(k2, msk);
+    merge_distinct(k1, k2, b1, b2);
+  }
+  if (lane == 0) {
+    const bool n1 = k1 == kNone64, n2 = k2 == kNone64;
+    out_idx[2 * (size_t)query + 0] = n1 ? ~0ull : (k1 & 0xFFFFFFFFull);
+    out_idx[2 * (size_t)query + 1] = n2 ? ~0ull : (k2 & 0xFFFFFFFFull);
+    // int -> float as reference src/CascadingHashNn.h:244; sentinel INT_MAX -> 2147483648.0f
+    out_dist[2 * (size_t)query + 0] = n1 ? 2147483648.0f : (float)(uint32_t)(k1 >> 32);
+    out_dist[2 * (size_t)query + 1] = n2 ? 2147483648.0f : (float)(uint32_t)(k2 >> 32);
+    if (out_ncand) out_ncand[query] = visited;
+  }
+}
+
+struct CascadeLayout {
+  int mc, hb;
+  size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart, off_cursor,
+      off_order, total;
+};
+
+CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
+  CascadeLayout L{};
+  L.mc = (m + 7) / 8 * 8;
+  L.hb = bucket_bits(m);
+  const size_t nb1 = ((size_t)1 << L.hb) + 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += round_up(std::max<size_t>(bytes, 16), 256);
+    return o;
+  };
+  L.off_dictp = take((size_t)n * dim * L.mc * sizeof(float));
+  L.off_ux = take((size_t)xrows * dim);
+  L.off_uy = take((size_t)yrows * dim);
+  L.off_xcodes = take((size_t)n * xrows * sizeof(uint32_t));
+  L.off_ysign = take((size_t)n * yrows * sizeof(uint32_t));
+  L.off_ymask = take((size_t)n * yrows * sizeof(uint32_t));
+  L.off_bstart = take((size_t)n * nb1 * sizeof(uint32_t));
+  L.off_cursor = take((size_t)n * nb1 * sizeof(uint32_t));
+  L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
+  L.total = off;
+  return L;
+}
+
+template <bool IS_QUERY>
+void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m, int n,
+                    const float *dictp, uint32_t *codes, uint32_t *masks, uint8_t *img,
+                    hipStream_t stream) {
+  if (nrows <= 0) return;
+  const dim3 grid((nrows + kThreads - 1) / kThreads), block(kThreads);
+  constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
+#define SPV_LAUNCH_PROJECT(MCV)                                                                 \
+  if (g <= G1)                                                                                  \
+    hipLaunchKernelGGL((project_kernel<MCV, IS_QUERY, G1>), grid, block, 0, stream, rows, nrows, \
+                       dim, m, n, g, dictp, codes, masks, img);                                 \
+  else                                                                                          \
+    hipLaunchKernelGGL((project_kernel<MCV, IS_QUERY, G2>), grid, block, 0, stream, rows, nrows, \
+                       dim, m, n, g, dictp, codes, masks, img);
+  switch (mc) {
+    case 8: SPV_LAUNCH_PROJECT(8) break;
+    case 16: SPV_LAUNCH_PROJECT(16) break;
+    case 24: SPV_LAUNCH_PROJECT(24) break;
+    default: SPV_LAUNCH_PROJECT(32) break;
+  }
+#undef SPV_LAUNCH_PROJECT
+}
+
+}  // namespace
+
+size_t cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g) {
+  (void)g;
+  return cascade_layout(xrows, yrows, dim, m, n).total;
+}
+
+int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int dim, int m, int n,
+                int g, const float *d_dict, uint64_t *d_idx, float *d_dist, int32_t *d_ncand,
+                void *d_ws, size_t ws_bytes, hipStream_t stream) {
+  if (yrows == 0) return SPV_OK;
+  if (!d_y || !d_dict || !d_idx || !d_dist || (xrows > 0 && !d_x))
+    return set_error(SPV_ERR_INVALID, "null device pointer");
+  if (g > 16) return set_error(SPV_ERR_INVALID, "num_candidate_neighbours g=%d > 16", g);
+  const CascadeLayout L = cascade_layout(xrows, yrows, dim, m, n);
+  if (!d_ws || ws_bytes < L.total)
+    return set_error(SPV_ERR_INVALID, "workspace too small: %zu < %zu", ws_bytes, L.total);
+  uint8_t *ws = static_cast<uint8_t *>(d_ws);
+  float *dictp = reinterpret_cast<float *>(ws + L.off_dictp);
+  uint8_t *ux = ws + L.off_ux;
+  uint8_t *uy = ws + L.off_uy;
+  uint32_t *xcodes = reinterpret_cast<uint32_t *>(ws + L.off_xcodes);
+  uint32_t *ysign = reinterpret_cast<uint32_t *>(ws + L.off_ysign);
+  uint32_t *ymask = reinterpret_cast<uint32_t *>(ws + L.off_ymask);
+  uint32_t *bstart = reinterpret_cast<uint32_t *>(ws + L.off_bstart);
+  uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.off_cursor);
+  uint32_t *order = reinterpret_cast<uint32_t *>(ws + L.off_order);
+  const int nb = 1 << L.hb;
+  const uint32_t hbmask = (uint32_t)nb - 1;
+
+  {
+  ProfScope prof("cascade_project", stream);
+  hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
+                     m, L.mc);
+  launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, stream);
+  launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, stream);
+  }
+  SPV_HIP_CHECK(hipGetLastError());
+
+  {
+  ProfScope prof("cascade_buckets", stream);
+  SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
+  if (xrows > 0)
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, xrows, n,
+                       hbmask, nb, bstart);
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(n), dim3(1024), 0, stream, bstart, cursor, nb);
+  if (xrows > 0)
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, xrows, n,
+                       hbmask, nb, cursor, order);
+  }
+  SPV_HIP_CHECK(hipGetLastError());
+
+  const dim3 grid((yrows + kThreads / 64 - 1) / (kThreads / 64)), block(kThreads);
+  const int cpl = (dim / 16 + 7) / 8;
+  if (cpl > 4)
+    return set_error(SPV_ERR_INVALID, "dim=%d > 512 is not supported by the cascade refine kernel",
+                     dim);
+  ProfScope prof_probe("cascade_probe_refine", stream);
+#define SPV_LAUNCH_PROBE(C)                                                                        \
+  hipLaunchKernelGGL((probe_refine_kernel<C>), grid, block, 0, stream, ux, uy, xrows, yrows, dim, \
+                     m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand)
+  if (cpl == 1)
+    SPV_LAUNCH_PROBE(1);
+  else if (cpl == 2)
+    SPV_LAUNCH_PROBE(2);
+  else
+    SPV_LAUNCH_PROBE(4);
+#undef SPV_LAUNCH_PROBE
+  SPV_HIP_CHECK(hipGetLastError());
+  return SPV_OK;
+}
+
+}  // namespace spv

@@ -1,0 +1,65 @@
+// common.h -- shared host-side helpers for libspectavi.so (gfx950 build).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/spectavi_amd.h"
+
+namespace spv {
+
+// Records status + message for the calling thread; returns `status`.
+int set_error(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+#define SPV_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      return ::spv::set_error(_e == hipErrorOutOfMemory ? SPV_ERR_NOMEM : SPV_ERR_HIP,   \
+                              "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                              __FILE__, __LINE__);                                       \
+    }                                                                                    \
+  } while (0)
+
+// Selects the process-wide device for host-pointer entry points on this thread.
+int ensure_device();
+
+// Brackets a kernel launch with hipEvents on `stream` while profiling is enabled.
+struct ProfScope {
+  ProfScope(const char *name, hipStream_t stream);
+  ~ProfScope();
+  const char *name_;
+  hipStream_t stream_;
+  hipEvent_t start_ = nullptr;
+};
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- L1 2-NN (l1k2.hip) -------------------------------------------------------------
+struct L1K2Plan {
+  int dim_pad;     // kernel row width in bytes (>= dim, zero padded)
+  int q;           // queries per lane
+  int slice_rows;  // database rows per slice (<= 65536)
+  int slices;      // number of database slices
+  int qblocks;     // query blocks
+  size_t pad_x_bytes, pad_y_bytes;  // padded copies (0 when dim == dim_pad)
+  size_t part_bytes;                // partial top-2 keys
+  size_t total_bytes;
+};
+L1K2Plan l1k2_plan(int xrows, int yrows, int dim);
+int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int dim,
+             uint64_t *d_idx, int32_t *d_dist, void *d_ws, size_t ws_bytes, hipStream_t stream);
+
+// ---- cascade hash (cascade.hip) -----------------------------------------------------
+size_t cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g);
+int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int dim, int m, int n,
+                int g, const float *d_dict, uint64_t *d_idx, float *d_dist, int32_t *d_ncand,
+                void *d_ws, size_t ws_bytes, hipStream_t stream);
+
+// ---- DLT (dlt.hip) ------------------------------------------------------------------
+int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x,
+            const double *d_xp, double *d_dst, bool want_error, hipStream_t stream);
+
+}  // namespace spv

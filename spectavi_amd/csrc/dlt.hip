@@ -1,0 +1,197 @@
+// dlt.hip -- batched two-view DLT triangulation for gfx950 (MI355X).
+//
+// Replaces the reference's serial per-point loop (src/Spectavi.cpp:48-51, :64-67)
+// around DltTriangulator::solve / reprojection_error
+// (src/DltTriangulator.h:36-74).  The reference runs Eigen::JacobiSVD on a
+// heap-allocated dynamic 4x4 per point; here one lane owns one point and the
+// whole 4x4 problem lives in registers (fp64):
+//
+//   A = [u P0[2]-P0[0]; v P0[2]-P0[1]; u' P1[2]-P1[0]; v' P1[2]-P1[1]]   (:51-54)
+//   one-sided (Hestenes) Jacobi: right rotations orthogonalise the columns of A,
+//   V accumulates them; the column of smallest norm is the right singular
+//   vector of the smallest singular value = V.col(3) of the reference (:56-58).
+//
+// The arithmetic is written without fused multiply-add (this file is compiled
+// with -ffp-contract=off) so that the CPU oracle, which executes the same
+// operation sequence, reproduces it bit for bit.
+//
+// Sign: Eigen's sign of V.col(3) is arbitrary; the result is canonicalised to
+// X[3] >= 0 (first nonzero component positive when X[3] == 0).
+
+#include "common.h"
+
+namespace spv {
+namespace {
+
+constexpr int kDltThreads = 256;
+constexpr int kMaxSweeps = 30;
+
+struct Cameras {
+  double p0[12];
+  double p1[12];
+};
+
+__device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double x1, double x2,
+                                          double y0, double y1, double y2, double (&X)[4],
+                                          double &u, double &v, double &up, double &vp) {
+  // hnormalize (reference src/DltTriangulator.h:38-45)
+  u = x0 / x2;
+  v = x1 / x2;
+  up = y0 / y2;
+  vp = y1 / y2;
+  double A[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    A[0][c] = u * cam.p0[8 + c] - cam.p0[0 + c];
+    A[1][c] = v * cam.p0[8 + c] - cam.p0[4 + c];
+    A[2][c] = up * cam.p1[8 + c] - cam.p1[0 + c];
+    A[3][c] = vp * cam.p1[8 + c] - cam.p1[4 + c];
+  }
+  double V[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
+
+  const double eps = 1e-15;
+  for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          alpha += A[i][p] * A[i][p];
+          beta += A[i][q] * A[i][q];
+          gamma += A[i][p] * A[i][q];
+        }
+        const double lim = eps * sqrt(alpha * beta);
+        if (fabs(gamma) > lim && gamma != 0.0) {
+          rotated = true;
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double tt = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double tn = zeta < 0.0 ? -tt : tt;
+          const double cs = 1.0 / sqrt(1.0 + tn * tn);
+          const double sn = cs * tn;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const double ap = A[i][p], aq = A[i][q];
+            A[i][p] = cs * ap - sn * aq;
+            A[i][q] = sn * ap + cs * aq;
+            const double vp_ = V[i][p], vq_ = V[i][q];
+            V[i][p] = cs * vp_ - sn * vq_;
+            V[i][q] = sn * vp_ + cs * vq_;
+          }
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+  // smallest column norm -> null direction
+  double best = 0.0;
+  int kbest = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double nn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nn += A[i][c] * A[i][c];
+    if (c == 0 || nn < best) {
+      best = nn;
+      kbest = c;
+    }
+  }
+  double xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    xv[i] = kbest == 0 ? V[i][0] : (kbest == 1 ? V[i][1] : (kbest == 2 ? V[i][2] : V[i][3]));
+  // renormalise (V is orthogonal up to rounding) and canonicalise the sign
+  double nrm = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nrm += xv[i] * xv[i];
+  nrm = sqrt(nrm);
+  bool neg = false;
+  if (xv[3] != 0.0)
+    neg = xv[3] < 0.0;
+  else if (xv[0] != 0.0)
+    neg = xv[0] < 0.0;
+  else if (xv[1] != 0.0)
+    neg = xv[1] < 0.0;
+  else
+    neg = xv[2] < 0.0;
+  const double scale = neg ? -nrm : nrm;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) X[i] = xv[i] / scale;
+}
+
+template <bool WANT_ERROR>
+__global__ __launch_bounds__(kDltThreads) void dlt_kernel(Cameras cam, long long npt,
+                                                          const double *__restrict__ x,
+                                                          const double *__restrict__ xp,
+                                                          double *__restrict__ dst) {
+  // coalesced staging: the block's 256 points are 256*3 contiguous doubles per view
+  __shared__ double sx[kDltThreads * 3];
+  __shared__ double sxp[kDltThreads * 3];
+  const long long base = (long long)blockIdx.x * kDltThreads;
+  const long long nblk = min((long long)kDltThreads, npt - base);
+  for (int e = threadIdx.x; e < nblk * 3; e += kDltThreads) {
+    sx[e] = x[base * 3 + e];
+    sxp[e] = xp[base * 3 + e];
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= nblk) return;
+  double X[4], u, v, up, vp;
+  dlt_solve(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1],
+            sxp[3 * t + 2], X, u, v, up, vp);
+  if (!WANT_ERROR) {
+    double4 *o = reinterpret_cast<double4 *>(dst) + (base + t);
+    *o = make_double4(X[0], X[1], X[2], X[3]);
+  } else {
+    // reference src/DltTriangulator.h:61-62, 67-74
+    double r0[3], r1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a += cam.p0[4 * r + c] * X[c];
+        b += cam.p1[4 * r + c] * X[c];
+      }
+      r0[r] = a;
+      r1[r] = b;
+    }
+    const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
+    const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
+    dst[base + t] = sqrt(e0x * e0x + e0y * e0y) + sqrt(e1x * e1x + e1y * e1y);
+  }
+}
+
+}  // namespace
+
+int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x,
+            const double *d_xp, double *d_dst, bool want_error, hipStream_t stream) {
+  if (npt < 0) return set_error(SPV_ERR_INVALID, "negative point count");
+  if (!P0 || !P1) return set_error(SPV_ERR_INVALID, "null camera pointer");
+  if (npt == 0) return SPV_OK;
+  if (!d_x || !d_xp || !d_dst) return set_error(SPV_ERR_INVALID, "null device pointer");
+  Cameras cam;
+  for (int i = 0; i < 12; ++i) {
+    cam.p0[i] = P0[i];
+    cam.p1[i] = P1[i];
+  }
+  const long long blocks = (npt + kDltThreads - 1) / kDltThreads;
+  if (blocks > 0x7FFFFFFFLL) return set_error(SPV_ERR_INVALID, "too many points");
+  ProfScope prof("dlt", stream);
+  if (want_error)
+    hipLaunchKernelGGL((dlt_kernel<true>), dim3((unsigned)blocks), dim3(kDltThreads), 0, stream,
+                       cam, npt, d_x, d_xp, d_dst);
+  else
+    hipLaunchKernelGGL((dlt_kernel<false>), dim3((unsigned)blocks), dim3(kDltThreads), 0, stream,
+                       cam, npt, d_x, d_xp, d_dst);
+  SPV_HIP_CHECK(hipGetLastError());
+  return SPV_OK;
+}
+
+}  // namespace spv

@@ -1,0 +1,486 @@
+// l1k2.hip -- exact all-pairs L1 (sum of absolute differences) 2-nearest-neighbour on
+// uint8 descriptors for gfx950 (MI355X).
+//
+// Replaces the loop nest of the reference's BruteForceNnL1K2::find_neighbours
+// <IdentityFilter> (reference src/BruteForceNnL1K2.h:84-145; SAD primitive
+// sad_16 at :43-48).  This is a new design, not a translation: the reference
+// keeps one query row resident and streams database rows past it with an
+// early-exit prune; here
+//
+//   * every lane owns Q query rows entirely in VGPRs (Q*dim/4 dwords),
+//   * a workgroup streams its database slice through LDS in 64-row tiles filled
+//     by coalesced 16-byte global loads (one descriptor = one 128-byte line),
+//   * all lanes of a wave read the SAME database row from LDS (broadcast
+//     ds_read_b128), so the LDS cost per row is amortised over 64*Q pairs,
+//   * the distance is accumulated by v_sad_hi_u8, which adds SAD<<16 into an
+//     accumulator pre-loaded with the tile-local row index: the accumulator IS
+//     the packed sort key (dist<<16 | idx16), no pack instruction needed,
+//   * the running two smallest keys per query are kept with v_min_u32 +
+//     v_med3_u32 (2 VALU ops per pair on top of the 32 SADs for dim=128),
+//   * no early-exit prune: it is result-neutral in the reference
+//     (src/BruteForceNnL1K2.h:118-121 only skips pairs that could not be
+//     inserted) and would diverge the wave.
+//
+// Keys are unique per database row, so "two smallest keys" is exactly the
+// reference's streaming strict-< update visited in ascending row order
+// (src/BruteForceNnL1K2.h:129-139): lexicographic (dist, idx).
+//
+// The database is cut into slices of <= 65536 rows (16-bit local index); a
+// second kernel merges the per-slice partial top-2 keys of each query with a
+// wavefront-shuffle argmin-2 butterfly and writes the ABI layout
+// (size_t idx[N,2], int dist[N,2]; sentinels INT_MAX / (size_t)-1 as
+// src/BruteForceNnL1K2.h:100-103).
+//
+// Roofline: sum-of-abs-diff is not a contraction (no MFMA); the bound is the
+// integer VALU: 32 v_sad lane-ops per 128-D pair.  See DESIGN.md.
+
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace spv {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileRows = 64;               // database rows per LDS tile
+constexpr uint32_t kKeyNone = 0xFFFFFFFFu;  // > any real key (dist <= 65280)
+constexpr uint64_t kKey64None = ~0ull;
+
+__device__ __forceinline__ uint32_t sad_hi(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_sad_hi_u8(a, b, c);  // (SAD_U8(a,b) << 16) + c
+}
+
+// Insert key k into the sorted pair (k1 <= k2).  min + med3.
+__device__ __forceinline__ void top2_insert(uint32_t &k1, uint32_t &k2, uint32_t k) {
+  k2 = max(min(k1, k), min(max(k1, k), k2));  // median of (k1, k, k2) -> v_med3_u32
+  k1 = min(k1, k);
+}
+
+template <int V4>
+__device__ __forceinline__ void lds_row(uint4 (&dst)[V4], const uint4 *row) {
+#pragma unroll
+  for (int c = 0; c < V4; ++c) dst[c] = row[c];
+}
+
+template <int D4, int Q>
+__device__ __forceinline__ void row_update(const uint32_t (&qreg)[Q][D4], const uint4 (&xr)[D4 / 4],
+                                           uint32_t j, uint32_t (&k1)[Q], uint32_t (&k2)[Q]) {
+  // Q independent accumulator chains, interleaved so consecutive v_sad_hi_u8
+  // never depend on each other.
+  uint32_t acc[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) acc[q] = j;
+#pragma unroll
+  for (int c = 0; c < D4 / 4; ++c) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][4 * c + 0], xr[c].x, acc[q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][4 * c + 1], xr[c].y, acc[q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][4 * c + 2], xr[c].z, acc[q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][4 * c + 3], xr[c].w, acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) top2_insert(k1[q], k2[q], acc[q]);
+}
+
+// Partial-key layout: part[(query * S + slice) * 2 + {0,1}], key = dist<<32 | global idx.
+__device__ __forceinline__ uint64_t widen_key(uint32_t k, uint32_t slice_base) {
+  if (k == kKeyNone) return kKey64None;
+  return ((uint64_t)(k >> 16) << 32) | (uint64_t)(slice_base + (k & 0xFFFFu));
+}
+
+// ---------------------------------------------------------------------------------
+// Tile kernel.  grid = (query blocks, slices); block = 256 threads = 4 waves.
+// Thread t of query block qb owns queries qb*256*Q + q*256 + t, q = 0..Q-1.
+// ---------------------------------------------------------------------------------
+template <int D4, int Q>
+__global__ __launch_bounds__(kThreads, 2) void l1k2_tile_kernel(
+    const uint4 *__restrict__ x, const uint4 *__restrict__ y, int M, int N, int slice_rows,
+    int S, uint64_t *__restrict__ part) {
+  constexpr int V4 = D4 / 4;                                   // 16-byte vectors per row
+  constexpr int TILE_V4 = kTileRows * V4;                      // vectors per tile
+  constexpr int NL = (TILE_V4 + kThreads - 1) / kThreads;      // staging loads per thread
+  __shared__ uint4 tile[2][TILE_V4];
+
+  const int t = threadIdx.x;
+  const int qb = blockIdx.x;
+  const int s = blockIdx.y;
+  const int row_begin = s * slice_rows;
+  const int row_end = min(M, row_begin + slice_rows);
+
+  // ---- this lane's queries -> registers
+  uint32_t qreg[Q][D4];
+  int qi[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    qi[q] = qb * (kThreads * Q) + q * kThreads + t;
+    const int src = min(qi[q], N - 1);
+    const uint4 *yr = y + (size_t)src * V4;
+#pragma unroll
+    for (int c = 0; c < V4; ++c) {
+      const uint4 v = yr[c];
+      qreg[q][4 * c + 0] = v.x;
+      qreg[q][4 * c + 1] = v.y;
+      qreg[q][4 * c + 2] = v.z;
+      qreg[q][4 * c + 3] = v.w;
+    }
+  }
+  uint32_t k1[Q], k2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) k1[q] = k2[q] = kKeyNone;
+
+  // ---- database slice through LDS, register-prefetched double buffer
+  uint4 stage[NL];
+  auto stage_load = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = t + i * kThreads;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < TILE_V4 && row0 + e / V4 < row_end) v = x[(size_t)row0 * V4 + e];
+      stage[i] = v;
+    }
+  };
+  auto stage_store = [&](uint4 *dst) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = t + i * kThreads;
+      if (e < TILE_V4) dst[e] = stage[i];
+    }
+  };
+
+  const int ntiles = (row_end - row_begin + kTileRows - 1) / kTileRows;
+  if (ntiles > 0) {
+    stage_load(row_begin);
+    stage_store(tile[0]);
+  }
+  __syncthreads();
+
+  for (int tl = 0; tl < ntiles; ++tl) {
+    const int row0 = row_begin + tl * kTileRows;
+    const bool has_next = tl + 1 < ntiles;
+    if (has_next) stage_load(row0 + kTileRows);
+
+    const int nrows = min(kTileRows, row_end - row0);
+    const uint4 *buf = tile[tl & 1];
+    const uint32_t jbase = (uint32_t)(row0 - row_begin);
+
+    // two rows per iteration, next row's LDS reads issued before the current
+    // row's SAD chain so the broadcast reads hide behind VALU work
+    uint4 xa[V4], xb[V4];
+    lds_row<V4>(xa, buf);
+    for (int r = 0; r < nrows; r += 2) {
+      lds_row<V4>(xb, buf + min(r + 1, kTileRows - 1) * V4);
+      row_update<D4, Q>(qreg, xa, jbase + r, k1, k2);
+      lds_row<V4>(xa, buf + min(r + 2, kTileRows - 1) * V4);
+      if (r + 1 < nrows) row_update<D4, Q>(qreg, xb, jbase + r + 1, k1, k2);
+    }
+
+    if (has_next) stage_store(tile[(tl + 1) & 1]);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (qi[q] < N) {
+      uint64_t *dst = part + ((size_t)qi[q] * S + s) * 2;
+      dst[0] = widen_key(k1[q], (uint32_t)row_begin);
+      dst[1] = widen_key(k2[q], (uint32_t)row_begin);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Experimental scalar-feed variant (SPECTAVI_L1K2_FEED=sgpr): the database row is
+// fetched with wave-uniform scalar loads (s_load_dwordx8/x16 through the scalar
+// cache) and enters v_sad_hi_u8 as an SGPR operand; no LDS, no barriers.
+// ---------------------------------------------------------------------------------
+template <int D4, int Q>
+__device__ __forceinline__ void row_update_s(const uint32_t (&qreg)[Q][D4], const uint32_t (&xs)[D4],
+                                             uint32_t j, uint32_t (&k1)[Q], uint32_t (&k2)[Q]) {
+  uint32_t acc[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) acc[q] = j;
+#pragma unroll
+  for (int i = 0; i < D4; ++i) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][i], xs[i], acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) top2_insert(k1[q], k2[q], acc[q]);
+}
+
+template <int D4, int Q>
+__global__ __launch_bounds__(kThreads, 2) void l1k2_tile_kernel_sfeed(
+    const uint32_t *__restrict__ x, const uint4 *__restrict__ y, int M, int N, int slice_rows,
+    int S, uint64_t *__restrict__ part) {
+  constexpr int V4 = D4 / 4;
+  const int t = threadIdx.x;
+  const int qb = blockIdx.x;
+  const int s = blockIdx.y;
+  const int row_begin = s * slice_rows;
+  const int row_end = min(M, row_begin + slice_rows);
+
+  uint32_t qreg[Q][D4];
+  int qi[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    qi[q] = qb * (kThreads * Q) + q * kThreads + t;
+    const int src = min(qi[q], N - 1);
+    const uint4 *yr = y + (size_t)src * V4;
+#pragma unroll
+    for (int c = 0; c < V4; ++c) {
+      const uint4 v = yr[c];
+      qreg[q][4 * c + 0] = v.x;
+      qreg[q][4 * c + 1] = v.y;
+      qreg[q][4 * c + 2] = v.z;
+      qreg[q][4 * c + 3] = v.w;
+    }
+  }
+  uint32_t k1[Q], k2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) k1[q] = k2[q] = kKeyNone;
+
+  const int nrows = row_end - row_begin;
+  if (nrows > 0) {
+    const uint32_t *xr = x + (size_t)row_begin * D4;
+    const uint32_t *xlast = x + (size_t)(row_end - 1) * D4;
+    uint32_t xa[D4], xb[D4];
+#pragma unroll
+    for (int i = 0; i < D4; ++i) xa[i] = xr[i];
+    for (int r = 0; r < nrows; r += 2) {
+      const uint32_t *x1 = (r + 1 < nrows) ? xr + D4 : xlast;
+#pragma unroll
+      for (int i = 0; i < D4; ++i) xb[i] = x1[i];
+      row_update_s<D4, Q>(qreg, xa, (uint32_t)r, k1, k2);
+      const uint32_t *x2 = (r + 2 < nrows) ? xr + 2 * D4 : xlast;
+#pragma unroll
+      for (int i = 0; i < D4; ++i) xa[i] = x2[i];
+      if (r + 1 < nrows) row_update_s<D4, Q>(qreg, xb, (uint32_t)(r + 1), k1, k2);
+      xr += 2 * D4;
+    }
+  }
+
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (qi[q] < N) {
+      uint64_t *dst = part + ((size_t)qi[q] * S + s) * 2;
+      dst[0] = widen_key(k1[q], (uint32_t)row_begin);
+      dst[1] = widen_key(k2[q], (uint32_t)row_begin);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Merge kernel: LPQ lanes per query stride over the S partial pairs, then an
+// argmin-2 butterfly over those lanes (wavefront shuffles).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void merge_pair(uint64_t &a1, uint64_t &a2, uint64_t b1, uint64_t b2) {
+  // (a1<=a2), (b1<=b2) -> two smallest of the four
+  const uint64_t lo = a1 < b1 ? a1 : b1;
+  const uint64_t hi = a1 < b1 ? b1 : a1;
+  const uint64_t m2 = a2 < b2 ? a2 : b2;
+  a1 = lo;
+  a2 = hi < m2 ? hi : m2;
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  const uint32_t lo = __shfl_xor((uint32_t)v, mask, 64);
+  const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <int LPQ>
+__global__ __launch_bounds__(kThreads) void l1k2_merge_kernel(const uint64_t *__restrict__ part,
+                                                              int N, int S,
+                                                              uint64_t *__restrict__ out_idx,
+                                                              int32_t *__restrict__ out_dist) {
+  const int gt = blockIdx.x * kThreads + threadIdx.x;
+  const int query = gt / LPQ;
+  const int sub = gt % LPQ;
+  uint64_t a1 = kKey64None, a2 = kKey64None;
+  if (query < N) {
+    const uint64_t *p = part + (size_t)query * S * 2;
+    for (int s = sub; s < S; s += LPQ) merge_pair(a1, a2, p[2 * s], p[2 * s + 1]);
+  }
+#pragma unroll
+  for (int m = 1; m < LPQ; m <<= 1) {
+    const uint64_t b1 = shfl_xor_u64(a1, m);
+    const uint64_t b2 = shfl_xor_u64(a2, m);
+    merge_pair(a1, a2, b1, b2);
+  }
+  if (query < N && sub == 0) {
+    const bool n1 = a1 == kKey64None, n2 = a2 == kKey64None;
+    out_idx[2 * (size_t)query + 0] = n1 ? ~0ull : (a1 & 0xFFFFFFFFull);
+    out_idx[2 * (size_t)query + 1] = n2 ? ~0ull : (a2 & 0xFFFFFFFFull);
+    out_dist[2 * (size_t)query + 0] = n1 ? 0x7FFFFFFF : (int32_t)(a1 >> 32);
+    out_dist[2 * (size_t)query + 1] = n2 ? 0x7FFFFFFF : (int32_t)(a2 >> 32);
+  }
+}
+
+// Zero-pad rows from `dim` to `dim_pad` bytes (L1 distances are unchanged).
+__global__ __launch_bounds__(kThreads) void pad_rows_kernel(const uint8_t *__restrict__ src,
+                                                            uint8_t *__restrict__ dst, size_t rows,
+                                                            int dim, int dim_pad) {
+  const size_t total = rows * (size_t)(dim_pad / 4);
+  for (size_t e = blockIdx.x * (size_t)kThreads + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * kThreads) {
+    const size_t r = e / (dim_pad / 4);
+    const int c = (int)(e % (dim_pad / 4)) * 4;
+    uint32_t v = 0;
+    if (c < dim) v = *reinterpret_cast<const uint32_t *>(src + r * dim + c);  // dim % 16 == 0
+    reinterpret_cast<uint32_t *>(dst)[e] = v;
+  }
+}
+
+// Experiment knobs (read once): SPECTAVI_L1K2_FEED=sgpr selects the scalar-feed
+// variant for dim 128; SPECTAVI_L1K2_Q / SPECTAVI_L1K2_BLOCKS override the plan.
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+static bool use_sfeed() {
+  static const bool on = [] {
+    const char *v = getenv("SPECTAVI_L1K2_FEED");
+    return v && v[0] == 's';
+  }();
+  return on;
+}
+
+template <int D4, int Q>
+void launch_tile(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Plan &p,
+                 uint64_t *part, hipStream_t stream) {
+  dim3 grid(p.qblocks, p.slices);
+  if constexpr (D4 == 32) {
+    if (use_sfeed()) {
+      hipLaunchKernelGGL((l1k2_tile_kernel_sfeed<D4, Q>), grid, dim3(kThreads), 0, stream,
+                         reinterpret_cast<const uint32_t *>(x),
+                         reinterpret_cast<const uint4 *>(y), M, N, p.slice_rows, p.slices, part);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((l1k2_tile_kernel<D4, Q>), grid, dim3(kThreads), 0, stream,
+                     reinterpret_cast<const uint4 *>(x), reinterpret_cast<const uint4 *>(y), M, N,
+                     p.slice_rows, p.slices, part);
+}
+
+template <int D4>
+void launch_tile_q(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Plan &p,
+                   uint64_t *part, hipStream_t stream) {
+  constexpr int QMAX = D4 <= 32 ? 4 : (D4 <= 48 ? 2 : 1);
+  if (p.q >= 4 && QMAX >= 4)
+    launch_tile<D4, (QMAX >= 4 ? 4 : 1)>(x, y, M, N, p, part, stream);
+  else if (p.q >= 2 && QMAX >= 2)
+    launch_tile<D4, (QMAX >= 2 ? 2 : 1)>(x, y, M, N, p, part, stream);
+  else
+    launch_tile<D4, 1>(x, y, M, N, p, part, stream);
+}
+
+int max_q_for(int dim_pad) { return dim_pad <= 128 ? 4 : (dim_pad <= 192 ? 2 : 1); }
+
+}  // namespace
+
+// Kernel row widths that are instantiated; other dims are zero-padded up.
+static int pick_dim_pad(int dim) {
+  static const int kDims[] = {64, 128, 144, 192, 256};
+  for (int d : kDims)
+    if (dim <= d) return d;
+  return -1;
+}
+
+L1K2Plan l1k2_plan(int xrows, int yrows, int dim) {
+  L1K2Plan p{};
+  p.dim_pad = pick_dim_pad(dim);
+  if (p.dim_pad < 0 || xrows < 0 || yrows < 0) return p;
+  const int qmax = max_q_for(p.dim_pad);
+  // queries per lane: as many as registers allow once there are enough queries
+  // to keep >= 512 workgroups of 256 lanes busy without it
+  int q = 1;
+  while (q * 2 <= qmax && (long long)yrows >= 512LL * kThreads * (q * 2) / 4) q *= 2;
+  static const int q_env = env_int("SPECTAVI_L1K2_Q", 0);
+  if (q_env == 1 || q_env == 2 || q_env == 4) q = std::min(q_env, qmax);
+  p.q = q;
+  p.qblocks = std::max(1, (yrows + kThreads * q - 1) / (kThreads * q));
+  // database slices: enough workgroups to fill 256 CUs x 2 several times over,
+  // each slice a multiple of the tile and <= 65536 rows (16-bit local index)
+  static const int want_blocks = std::max(1, env_int("SPECTAVI_L1K2_BLOCKS", 2048));
+  int s_target = std::max(1, (want_blocks + p.qblocks - 1) / p.qblocks);
+  long long rows = (xrows + s_target - 1) / s_target;
+  rows = (rows + kTileRows - 1) / kTileRows * kTileRows;
+  rows = std::min<long long>(std::max<long long>(rows, kTileRows), 65536);
+  p.slice_rows = (int)rows;
+  p.slices = std::max(1, (int)((xrows + rows - 1) / rows));
+  if (p.dim_pad != dim) {
+    p.pad_x_bytes = round_up((size_t)xrows * p.dim_pad, 256);
+    p.pad_y_bytes = round_up((size_t)yrows * p.dim_pad, 256);
+  }
+  p.part_bytes = round_up((size_t)std::max(yrows, 1) * p.slices * 2 * sizeof(uint64_t), 256);
+  p.total_bytes = p.pad_x_bytes + p.pad_y_bytes + p.part_bytes;
+  return p;
+}
+
+int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int dim,
+             uint64_t *d_idx, int32_t *d_dist, void *d_ws, size_t ws_bytes, hipStream_t stream) {
+  if (xrows < 0 || yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  if (dim <= 0 || dim % 16 != 0)
+    return set_error(SPV_ERR_INVALID,
+                     "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
+  if (dim > 256)
+    return set_error(SPV_ERR_INVALID, "dim=%d > 256 is not supported by the gfx950 L1 kernel", dim);
+  if (yrows == 0) return SPV_OK;
+  if (!d_y || !d_idx || !d_dist || (xrows > 0 && !d_x))
+    return set_error(SPV_ERR_INVALID, "null device pointer");
+  const L1K2Plan p = l1k2_plan(xrows, yrows, dim);
+  if (ws_bytes < p.total_bytes || !d_ws)
+    return set_error(SPV_ERR_INVALID, "workspace too small: %zu < %zu", ws_bytes, p.total_bytes);
+
+  uint8_t *ws = static_cast<uint8_t *>(d_ws);
+  const uint8_t *kx = d_x, *ky = d_y;
+  if (p.dim_pad != dim) {
+    uint8_t *px = ws;
+    uint8_t *py = ws + p.pad_x_bytes;
+    if (xrows > 0)
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(kThreads), 0, stream, d_x, px,
+                         (size_t)xrows, dim, p.dim_pad);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(kThreads), 0, stream, d_y, py,
+                       (size_t)yrows, dim, p.dim_pad);
+    kx = px;
+    ky = py;
+  }
+  uint64_t *part = reinterpret_cast<uint64_t *>(ws + p.pad_x_bytes + p.pad_y_bytes);
+
+  {
+    ProfScope prof("l1k2_tile", stream);
+  switch (p.dim_pad) {
+    case 64: launch_tile_q<16>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 128: launch_tile_q<32>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 144: launch_tile_q<36>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 192: launch_tile_q<48>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 256: launch_tile_q<64>(kx, ky, xrows, yrows, p, part, stream); break;
+    default: return set_error(SPV_ERR_INVALID, "internal: bad dim_pad %d", p.dim_pad);
+  }
+  }
+  SPV_HIP_CHECK(hipGetLastError());
+
+  ProfScope prof_merge("l1k2_merge", stream);
+
+  if (p.slices <= 4) {
+    const int blocks = (yrows + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL((l1k2_merge_kernel<1>), dim3(blocks), dim3(kThreads), 0, stream, part, yrows,
+                       p.slices, d_idx, d_dist);
+  } else if (p.slices <= 32) {
+    const int blocks = (int)(((long long)yrows * 8 + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL((l1k2_merge_kernel<8>), dim3(blocks), dim3(kThreads), 0, stream, part, yrows,
+                       p.slices, d_idx, d_dist);
+  } else {
+    const int blocks = (int)(((long long)yrows * 64 + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL((l1k2_merge_kernel<64>), dim3(blocks), dim3(kThreads), 0, stream, part,
+                       yrows, p.slices, d_idx, d_dist);
+  }
+  SPV_HIP_CHECK(hipGetLastError());
+  return SPV_OK;
+}
+
+}  // namespace spv

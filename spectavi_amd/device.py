@@ -1,0 +1,142 @@
+"""Device-resident entry points: torch tensors in HBM in, torch tensors out.
+
+Thin binding of section 3 of include/spectavi_amd.h (spv_*_device).  torch is
+used only for device memory and the current HIP stream; every kernel launched
+here is hand-written HIP inside libspectavi.so and is enqueued on torch's
+current stream, so `torch.cuda.Event` timing and stream ordering apply.
+"""
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from spectavi_amd._lib import clib, check
+
+_vp = ct.c_void_p
+
+clib.spv_l1k2_workspace_bytes.restype = ct.c_size_t
+clib.spv_l1k2_workspace_bytes.argtypes = [ct.c_int, ct.c_int, ct.c_int]
+clib.spv_l1k2_device.restype = ct.c_int
+clib.spv_l1k2_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, ct.c_size_t, _vp]
+clib.spv_cascade_workspace_bytes.restype = ct.c_size_t
+clib.spv_cascade_workspace_bytes.argtypes = [ct.c_int] * 6
+clib.spv_cascade_device.restype = ct.c_int
+clib.spv_cascade_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int,
+                                    _vp, _vp, _vp, _vp, _vp, ct.c_size_t, _vp]
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+clib.spv_dlt_triangulate_device.restype = ct.c_int
+clib.spv_dlt_triangulate_device.argtypes = [_f64p, _f64p, ct.c_longlong, _vp, _vp, _vp, _vp]
+clib.spv_dlt_reprojection_error_device.restype = ct.c_int
+clib.spv_dlt_reprojection_error_device.argtypes = [_f64p, _f64p, ct.c_longlong, _vp, _vp, _vp, _vp]
+clib.spv_profile_enable.restype = None
+clib.spv_profile_enable.argtypes = [ct.c_int]
+clib.spv_profile_read.restype = ct.c_int
+clib.spv_profile_read.argtypes = [ct.c_char_p, ct.POINTER(ct.c_longlong), ct.POINTER(ct.c_double)]
+clib.spv_profile_reset.restype = None
+clib.spv_profile_reset.argtypes = []
+
+
+def _stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous %s tensor on the GPU" % (name, dtype))
+
+
+class Workspace:
+    """Grow-only scratch buffer reused across calls (one per device)."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
+            self._buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._buf
+
+
+_default_ws = Workspace()
+
+
+def l1k2(x, y, workspace=None):
+    """Exact L1 2-NN on device: x uint8 [M,D], y uint8 [N,D] (CUDA tensors).
+    Returns (idx int64 [N,2] -- the ABI's size_t bits, -1 = no neighbour --,
+    dist int32 [N,2]).  Asynchronous on the current stream."""
+    _need(x, torch.uint8, "x")
+    _need(y, torch.uint8, "y")
+    xrows, dim = x.shape
+    yrows, ydim = y.shape
+    assert dim == ydim
+    if dim % 16 != 0:
+        raise ValueError("Input matrix inner dimensions must be 16-byte aligned.")
+    idx = torch.empty((yrows, 2), dtype=torch.int64, device=y.device)
+    dist = torch.empty((yrows, 2), dtype=torch.int32, device=y.device)
+    nbytes = clib.spv_l1k2_workspace_bytes(xrows, yrows, dim)
+    ws = (workspace or _default_ws).get(nbytes, y.device)
+    check(clib.spv_l1k2_device(x.data_ptr(), y.data_ptr(), xrows, yrows, dim, idx.data_ptr(),
+                               dist.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    return idx, dist
+
+
+def cascade(x, y, hash_dict, g=2, workspace=None, want_ncand=False):
+    """Cascade-hash 2-NN on device: x,y float32 [rows,D]; hash_dict float32 [n,D,m]."""
+    _need(x, torch.float32, "x")
+    _need(y, torch.float32, "y")
+    _need(hash_dict, torch.float32, "hash_dict")
+    xrows, dim = x.shape
+    yrows, ydim = y.shape
+    n, ddim, m = hash_dict.shape
+    assert dim == ydim == ddim
+    idx = torch.empty((yrows, 2), dtype=torch.int64, device=y.device)
+    dist = torch.empty((yrows, 2), dtype=torch.float32, device=y.device)
+    ncand = torch.empty((yrows,), dtype=torch.int32, device=y.device) if want_ncand else None
+    nbytes = clib.spv_cascade_workspace_bytes(xrows, yrows, dim, m, n, g)
+    ws = (workspace or _default_ws).get(nbytes, y.device)
+    check(clib.spv_cascade_device(x.data_ptr(), y.data_ptr(), xrows, yrows, dim, m, n, g,
+                                  hash_dict.data_ptr(), idx.data_ptr(), dist.data_ptr(),
+                                  ncand.data_ptr() if want_ncand else None, ws.data_ptr(),
+                                  ws.numel(), _stream()))
+    return (idx, dist, ncand) if want_ncand else (idx, dist)
+
+
+def _dlt(fn, P0, P1, x, xp, cols):
+    _need(x, torch.float64, "x")
+    _need(xp, torch.float64, "xp")
+    assert x.shape == xp.shape and x.shape[1] == 3
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    P1 = np.ascontiguousarray(P1, dtype=np.float64)
+    assert P0.shape == (3, 4) and P1.shape == (3, 4)
+    npt = x.shape[0]
+    dst = torch.empty((npt, cols), dtype=torch.float64, device=x.device)
+    check(fn(P0, P1, npt, x.data_ptr(), xp.data_ptr(), dst.data_ptr(), _stream()))
+    return dst
+
+
+def dlt_triangulate(P0, P1, x, xp):
+    """P0,P1 host float64 [3,4]; x,xp CUDA float64 [npt,3] -> CUDA float64 [npt,4]."""
+    return _dlt(clib.spv_dlt_triangulate_device, P0, P1, x, xp, 4)
+
+
+def dlt_reprojection_error(P0, P1, x, xp):
+    return _dlt(clib.spv_dlt_reprojection_error_device, P0, P1, x, xp, 1)
+
+
+def profile_enable(on=True):
+    """Bracket the hot kernels with HIP events on their launch stream."""
+    clib.spv_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    clib.spv_profile_reset()
+
+
+def profile_read(name):
+    """(launch count, total milliseconds) of the named kernel since the last reset.
+    Synchronises with the recorded events."""
+    n = ct.c_longlong(0)
+    ms = ct.c_double(0.0)
+    check(clib.spv_profile_read(name.encode(), ct.byref(n), ct.byref(ms)))
+    return int(n.value), float(ms.value)

@@ -1,0 +1,68 @@
+"""
+``spectavi_amd.mvg``
+====================
+Multi-view-geometry front-end: the batched DLT triangulator of the reference's
+``spectavi.mvg`` (reference spectavi/mvg.py:259-306), bound to the gfx950 build
+of ``libspectavi.so``.
+"""
+import ctypes as ct
+
+import numpy as np
+from numpy.ctypeslib import ndpointer
+
+from spectavi_amd._lib import clib, check
+
+
+def hnormalize(x):
+    """Homogeneous -> euclidean (reference spectavi/mvg.py:14-18)."""
+    return x[..., :-1] / np.expand_dims(x[..., -1], axis=-1)
+
+
+_dlt_triangulate = clib.dlt_triangulate
+_dlt_triangulate.restype = None
+_dlt_triangulate.argtypes = [ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                             ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                             ct.c_int,
+                             ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                             ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                             ndpointer(ct.c_double, flags="C_CONTIGUOUS"), ]
+
+_dlt_reprojection_error = clib.dlt_reprojection_error
+_dlt_reprojection_error.restype = None
+_dlt_reprojection_error.argtypes = list(_dlt_triangulate.argtypes)
+
+
+def dlt_triangulate(P0, P1, x, xp, ret_error=False):
+    """
+    Triangulate `npt` two-view correspondences (reference spectavi/mvg.py:282-302).
+
+    P0, P1 : float64 [3,4] camera matrices; x, xp : float64 [npt,3] (or [3])
+    homogeneous image points.  Returns float64 [npt,4] unit-norm homogeneous
+    points (sign canonicalised to X[3] >= 0), or [npt,1] reprojection errors
+    with `ret_error=True`.
+    """
+    if not (P0.shape == (3, 4) and P1.shape == (3, 4)):
+        raise TypeError('P0,P1 must be camera matrices.')
+    if len(x.shape) == 1:
+        x = np.expand_dims(x, axis=0)
+    if len(xp.shape) == 1:
+        xp = np.expand_dims(xp, axis=0)
+    if not (x.shape[0] == xp.shape[0]):
+        raise TypeError('Must be same # points or shape.')
+    if not (len(x.shape) == 2 and len(xp.shape) == 2):
+        raise TypeError('Wrong dimensionality of input.')
+    if not (x.shape[1] == 3 and xp.shape[1] == 3):
+        raise TypeError('Coords must be homogenous.')
+    npt = x.shape[0]
+    if ret_error:
+        dst = np.empty((npt, 1))
+        _dlt_reprojection_error(P0, P1, npt, x, xp, dst)
+    else:
+        dst = np.empty((npt, 4))
+        _dlt_triangulate(P0, P1, npt, x, xp, dst)
+    check()
+    return dst
+
+
+def dlt_reprojection_error(P0, P1, x, xp):
+    return dlt_triangulate(P0, P1, x, xp, ret_error=True)

@@ -1,0 +1,74 @@
+"""GPU parity: cascade-hash prefilter + L1 refine through the C-ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_2k(golden):
+    from spectavi_amd import feature
+    g = golden("cascade_2kx2k_m8n2g2.npz")
+    x, y = g["x"].astype(np.float32), g["y"].astype(np.float32)
+    idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, g["dict"], g=int(g["g"]), return_ncand=True)
+    assert idx.dtype == np.uint64 and dist.dtype == np.float32
+    assert np.array_equal(dist, g["dist"])
+    assert np.array_equal(idx, g["idx"])
+    assert np.array_equal(ncand, g["ncand"])
+
+
+@pytest.mark.parametrize("m_rows,n_rows,dim,m,n,g", [
+    (2000, 1500, 128, 8, 2, 2), (5000, 3000, 128, 10, 2, 2), (3000, 1000, 128, 6, 3, 0),
+    (1000, 777, 144, 8, 16, 5),   # the reference test's parameters (m=8, n=16, g=5), dim 144
+    (4000, 500, 128, 3, 1, 1),    # huge buckets: overflows the LDS candidate list
+    (3000, 600, 128, 25, 2, 3),   # m > bucket bits: full-code check path
+    (50, 40, 16, 4, 2, 2), (1, 5, 32, 4, 2, 1), (0, 5, 32, 4, 2, 1), (900, 300, 256, 7, 2, 2),
+])
+def test_matches_oracle(oracle, m_rows, n_rows, dim, m, n, g):
+    from spectavi_amd import feature
+    rng = np.random.default_rng(m_rows + 3 * n_rows + dim + m)
+    x = rng.integers(-128, 128, (m_rows, dim)).astype(np.float32)
+    y = rng.integers(-128, 128, (n_rows, dim)).astype(np.float32)
+    k = min(m_rows, n_rows) // 2
+    if k:
+        y[:k] = np.clip(x[rng.integers(0, m_rows, k)] + rng.integers(-2, 3, (k, dim)), -128, 127)
+    d = rng.standard_normal((n, dim, m)).astype(np.float32)
+    idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+    oidx, odist, oncand, onset = oracle.nn_cascading_hash(x, y, m, n, g, d)
+    assert np.array_equal(ncand, oncand)
+    assert np.array_equal(dist, odist)
+    assert np.array_equal(idx, oidx)
+
+
+def test_reference_symbol_and_fallback(oracle):
+    """nn_cascading_hash (NdArray path, library-drawn hyperplanes from a fixed seed) and the
+    m<4 brute-force fallback of the front-end (reference spectavi/feature.py:364-371)."""
+    import spectavi_amd
+    from spectavi_amd import feature
+    rng = np.random.default_rng(5)
+    x = rng.integers(-128, 128, (3000, 128)).astype(np.float32)
+    y = rng.integers(-128, 128, (1000, 128)).astype(np.float32)
+    y[:500] = np.clip(x[rng.integers(0, 3000, 500)] + rng.integers(-2, 3, (500, 128)), -128, 127)
+    spectavi_amd.set_hash_seed(42)
+    try:
+        idx, dist = feature.nn_cascading_hash(x, y)          # m auto = 8, n = 2, g = 2
+        d = feature.generate_hash_dict(42, 128, 8, 2)
+    finally:
+        spectavi_amd.set_hash_seed(None)
+    oidx, odist, _, _ = oracle.nn_cascading_hash(x, y, 8, 2, 2, d)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    xs, ys = x[:60], y[:50]                                   # m = 3 < 4 -> brute force, int32 dists
+    idx, dist = feature.nn_cascading_hash(xs, ys)
+    oidx, odist = oracle.nn_bruteforcel1k2((xs + 128).astype(np.uint8), (ys + 128).astype(np.uint8))
+    assert dist.dtype == np.int32 and np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+
+
+def test_reference_test_recall_bound(golden):
+    """reference test/test_feature.py:123-151 on the HIP path."""
+    from oracle.oracle import numpy_l1_top2
+    from spectavi_amd import feature
+    g = golden("cascade_ref_test_inputs.npz")
+    x = feature.normalize_to_ubyte_and_multiple_16_dim(g["x"])
+    y = feature.normalize_to_ubyte_and_multiple_16_dim(g["y"])
+    nni, nnd = feature.nn_cascading_hash(x, y, m=8, n=16, g=5)
+    gt_nni, _ = numpy_l1_top2((x + 128).astype(np.uint8), (y + 128).astype(np.uint8))
+    assert np.sum(gt_nni != nni) <= 2 * round(.4 * 200)

@@ -1,0 +1,130 @@
+"""GPU parity: the HIP L1 2-NN path, called through the C-ABI, against the CPU oracle,
+the golden fixtures and size-independent properties at BASELINE sizes."""
+import numpy as np
+import pytest
+
+from tests.conftest import uniform_u8
+
+pytestmark = pytest.mark.gpu
+
+U64MAX = np.iinfo(np.uint64).max
+I32MAX = np.iinfo(np.int32).max
+
+
+def _raw(x, y):
+    """spv_nn_bruteforcel1k2: host pointers, caller-allocated outputs."""
+    import ctypes as ct
+    from spectavi_amd._lib import clib, check
+    x = np.ascontiguousarray(x)
+    y = np.ascontiguousarray(y)
+    idx = np.empty((y.shape[0], 2), np.uint64)
+    dist = np.empty((y.shape[0], 2), np.int32)
+    clib.spv_nn_bruteforcel1k2.restype = ct.c_int
+    clib.spv_nn_bruteforcel1k2.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int,
+                                           ct.c_void_p, ct.c_void_p]
+    check(clib.spv_nn_bruteforcel1k2(x.ctypes.data, y.ctypes.data, x.shape[0], y.shape[0], y.shape[1],
+                                     idx.ctypes.data, dist.ctypes.data))
+    return idx, dist
+
+
+@pytest.mark.parametrize("name", ["l1k2_200x144.npz", "l1k2_1kx1k_128.npz", "l1k2_ties_300x500_64.npz",
+                                  "l1k2_dups_257x5_128.npz", "l1k2_m0.npz", "l1k2_m1.npz", "l1k2_m2.npz"])
+def test_golden_through_reference_symbol(golden, name):
+    """nn_bruteforcel1k2 (NdArray out-params), the symbol the reference front-end binds."""
+    from spectavi_amd import feature
+    g = golden(name)
+    idx, dist = feature.nn_bruteforcel1k2(g["x"], g["y"])
+    assert idx.dtype == np.uint64 and dist.dtype == np.int32 and idx.shape == (g["y"].shape[0], 2)
+    assert np.array_equal(dist, g["dist"])  # what the reference's own test checks
+    assert np.array_equal(idx, g["idx"])    # bit-exact indices, lexicographic ties
+
+
+@pytest.mark.parametrize("m,n,dim,hi", [
+    (1000, 1000, 128, 256),   # BASELINE config 1
+    (200, 200, 144, 256),     # the reference's test shape (dim 144)
+    (777, 333, 128, 256),     # ragged vs tile/block sizes
+    (65, 1, 128, 256), (63, 257, 128, 3), (1, 1, 16, 256), (2, 3, 32, 256),
+    (130, 70, 64, 2), (500, 300, 48, 256), (300, 100, 80, 256), (300, 100, 160, 256),
+    (300, 100, 192, 256), (300, 100, 208, 256), (300, 100, 256, 256),
+    (70000, 300, 128, 256),   # more than one 65536-row slice limit worth of rows
+    (4096, 5000, 128, 2),     # tie-heavy at a size with several slices
+])
+def test_matches_oracle(oracle, m, n, dim, hi):
+    rng = np.random.default_rng(m * 131 + n * 7 + dim)
+    x = rng.integers(0, hi, (m, dim), dtype=np.uint8)
+    y = rng.integers(0, hi, (n, dim), dtype=np.uint8)
+    idx, dist = _raw(x, y)
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+    assert np.array_equal(dist, odist)
+    assert np.array_equal(idx, oidx)
+
+
+def test_max_distance_and_extremes(oracle):
+    x = np.zeros((300, 256), np.uint8)
+    y = np.full((5, 256), 255, np.uint8)  # 256 * 255 = 65280: largest key that must fit 16 bits
+    x[7, :3] = 1
+    idx, dist = _raw(x, y)
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist) and dist[0, 1] == 65280
+
+
+def test_empty_and_sentinels():
+    y = uniform_u8(1, 9, 32)
+    idx, dist = _raw(np.zeros((0, 32), np.uint8), y)
+    assert np.all(idx == U64MAX) and np.all(dist == I32MAX)
+    idx, dist = _raw(uniform_u8(2, 1, 32), y)
+    assert np.all(idx[:, 0] == 0) and np.all(idx[:, 1] == U64MAX) and np.all(dist[:, 1] == I32MAX)
+    idx, dist = _raw(uniform_u8(2, 5, 32), np.zeros((0, 32), np.uint8))
+    assert idx.shape == (0, 2)
+
+
+def test_errors_are_reported_not_thrown():
+    from spectavi_amd._lib import SpectaviError
+    with pytest.raises(SpectaviError):
+        _raw(np.zeros((4, 24), np.uint8), np.zeros((4, 24), np.uint8))
+    with pytest.raises(SpectaviError):
+        _raw(np.zeros((4, 272), np.uint8), np.zeros((4, 272), np.uint8))
+
+
+def test_device_path_and_variants(oracle, monkeypatch):
+    """spv_l1k2_device on resident tensors; every queries-per-lane variant gives the same bits."""
+    import torch
+    from spectavi_amd import device
+    x = uniform_u8(5, 3000, 128)
+    y = uniform_u8(6, 2500, 128)
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    idx, dist = device.l1k2(xd, yd)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist.cpu().numpy(), odist)
+
+
+def test_full_size_properties_256k(oracle):
+    """BASELINE config 2 (256k x 256k, D=128) through size-independent properties:
+    planted exact copies are found at distance 0, results are sorted, and a query
+    subsample agrees with the oracle bit for bit."""
+    import torch
+    from spectavi_amd import device
+    n = 262144
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randint(0, 256, (n, 128), dtype=torch.uint8, device="cuda", generator=g)
+    y = torch.randint(0, 256, (n, 128), dtype=torch.uint8, device="cuda", generator=g)
+    planted = torch.arange(0, n, 1021, device="cuda")
+    src = (planted * 7919) % n
+    y[planted] = x[src]
+    idx, dist = device.l1k2(x, y)
+    torch.cuda.synchronize()
+    assert bool((dist[:, 0] <= dist[:, 1]).all())
+    assert bool((dist[planted, 0] == 0).all()) and bool((idx[planted, 0] == src).all())
+    assert bool((idx >= 0).all()) and bool((idx < n).all()) and bool((idx[:, 0] != idx[:, 1]).all())
+    # the distance reported for (query, idx) is the true L1 distance of that pair
+    sel = torch.arange(0, n, 257, device="cuda")
+    for c in range(2):
+        d = (x[idx[sel, c]].to(torch.int32) - y[sel].to(torch.int32)).abs().sum(1)
+        assert bool((d == dist[sel, c]).all())
+    # oracle on a 512-query subsample against the full database
+    sub = np.arange(0, n, 512)
+    oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y[sub].cpu().numpy(), nthreads=oracle.max_threads())
+    assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist[sub].cpu().numpy(), odist)

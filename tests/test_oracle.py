@@ -1,0 +1,141 @@
+"""CPU-only: pins the oracle (oracle/) against the reference's own test properties,
+the independent numpy statements and the committed golden fixtures."""
+import numpy as np
+import pytest
+
+from tests.conftest import uniform_u8
+
+
+def test_l1k2_reference_test_property(oracle):
+    """reference test/test_feature.py:102-121: 200x144 uniform uint8, distances equal
+    the numpy brute-force L1 exactly (the reference compares distances only)."""
+    np.random.seed(0xdeadbeef)
+    x = np.random.uniform(low=0, high=256, size=(200, 144)).astype('uint8')
+    y = np.random.uniform(low=0, high=256, size=(200, 144)).astype('uint8')
+    _, nnd = oracle.nn_bruteforcel1k2(x, y)
+    d = np.abs(x.astype(np.int32)[:, None, :] - y.astype(np.int32)[None, :, :]).sum(-1)
+    gt = np.sort(d, axis=0)[:2].T
+    assert np.sum(np.abs(gt - nnd) > 0) == 0
+
+
+@pytest.mark.parametrize("seed,m,n,dim,hi", [(1, 64, 33, 16, 256), (2, 300, 200, 64, 2), (3, 1, 5, 32, 256),
+                                            (4, 2, 5, 128, 4), (5, 513, 129, 128, 256)])
+def test_l1k2_matches_numpy_indices(oracle, seed, m, n, dim, hi):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, hi, (m, dim), dtype=np.uint8)
+    y = rng.integers(0, hi, (n, dim), dtype=np.uint8)
+    idx, dist = oracle.nn_bruteforcel1k2(x, y, nthreads=4)
+    nidx, ndist = oracle.numpy_l1_top2(x, y)
+    assert np.array_equal(dist, ndist)
+    assert np.array_equal(idx, nidx)  # lexicographic (dist, idx), lower index on ties
+
+
+def test_l1k2_hand_checked_ties(oracle):
+    """Streaming strict-< update (reference src/BruteForceNnL1K2.h:129-139) worked by
+    hand on distance sequences [5,3,3,5], [3,5,5], [5,5,3]."""
+    def rows(ds):
+        x = np.zeros((len(ds), 16), np.uint8)
+        x[:, 0] = ds
+        return x
+    y = np.zeros((1, 16), np.uint8)
+    for ds, want_i, want_d in [([5, 3, 3, 5], [1, 2], [3, 3]), ([3, 5, 5], [0, 1], [3, 5]),
+                               ([5, 5, 3], [2, 0], [3, 5])]:
+        idx, dist = oracle.nn_bruteforcel1k2(rows(ds), y)
+        assert idx[0].tolist() == want_i and dist[0].tolist() == want_d
+
+
+def test_l1k2_sentinels_and_threads(oracle):
+    y = uniform_u8(1, 7, 32)
+    idx, dist = oracle.nn_bruteforcel1k2(np.zeros((0, 32), np.uint8), y)
+    assert np.all(idx == np.iinfo(np.uint64).max) and np.all(dist == np.iinfo(np.int32).max)
+    x = uniform_u8(2, 1, 32)
+    idx, dist = oracle.nn_bruteforcel1k2(x, y)
+    assert np.all(idx[:, 0] == 0) and np.all(idx[:, 1] == np.iinfo(np.uint64).max)
+    assert np.all(dist[:, 1] == np.iinfo(np.int32).max)
+    x = uniform_u8(3, 400, 128)
+    y = uniform_u8(4, 300, 128)
+    a = oracle.nn_bruteforcel1k2(x, y, nthreads=1)
+    b = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        oracle.nn_bruteforcel1k2(np.zeros((4, 24), np.uint8), np.zeros((4, 24), np.uint8))
+
+
+@pytest.mark.parametrize("name", ["l1k2_200x144.npz", "l1k2_1kx1k_128.npz", "l1k2_ties_300x500_64.npz",
+                                  "l1k2_dups_257x5_128.npz", "l1k2_m0.npz", "l1k2_m1.npz", "l1k2_m2.npz"])
+def test_l1k2_golden(oracle, golden, name):
+    g = golden(name)
+    idx, dist = oracle.nn_bruteforcel1k2(g["x"], g["y"], nthreads=4)
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
+
+
+def test_cascade_reference_test_bound(oracle, golden):
+    """reference test/test_feature.py:123-151: 200x144 randn -> normalize, m=8 n=16 g=5,
+    at most 2*round(.4*200) of the 400 index entries differ from exact L1."""
+    from oracle.oracle import numpy_l1_top2
+    g = golden("cascade_ref_test_inputs.npz")
+
+    def normalize(x):  # reference spectavi/feature.py:384-407 restated in numpy
+        x0 = x - np.mean(x, axis=0, keepdims=True)
+        norm = np.max(np.stack([np.max(x0, 0, keepdims=True), -np.min(x0, 0, keepdims=True)]), axis=0)
+        x0 = np.clip(np.round(x0 / norm * 128), -128, 127)
+        return x0.astype(np.float32)
+    x, y = normalize(g["x"]), normalize(g["y"])
+    idx, dist, ncand, nset = oracle.nn_cascading_hash(x, y, 8, 16, 5, g["dict"])
+    gt_idx, gt_dist = numpy_l1_top2((x + 128).astype(np.uint8), (y + 128).astype(np.uint8))
+    assert np.sum(idx != gt_idx) <= 2 * round(.4 * 200)
+    # every returned pair is a true L1 distance of that pair
+    xi, yi = x.astype(np.int32), y.astype(np.int32)
+    ok = idx != np.iinfo(np.uint64).max
+    for q in range(200):
+        for c in range(2):
+            if ok[q, c]:
+                assert dist[q, c] == np.abs(xi[int(idx[q, c])] - yi[q]).sum()
+
+
+def test_cascade_candidates_closed_form(oracle, golden):
+    """The bucket/multi-probe restatement (src/CascadingHashNn.h:150-227) equals the closed
+    form ((xcode ^ ysign) & ~ymask) == 0, and the result is the lexicographic top-2 over it."""
+    g = golden("cascade_2kx2k_m8n2g2.npz")
+    x, y = g["x"].astype(np.float32), g["y"].astype(np.float32)
+    m, n, gg = int(g["m"]), int(g["n"]), int(g["g"])
+    idx, dist, ncand, nset, xcodes, ysign, ymask = oracle.nn_cascading_hash(x, y, m, n, gg, g["dict"], debug=True)
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
+    assert np.array_equal(xcodes, g["xcodes"]) and np.array_equal(ymask, g["ymask"])
+    cand = oracle.candidates_from_codes(xcodes, ysign, ymask)
+    assert np.array_equal(cand.sum(1), nset)
+    assert np.all([bin(int(v)).count("1") == gg for v in ymask.ravel()])
+    ux, uy = (x + 128).astype(np.int32), (y + 128).astype(np.int32)
+    for q in range(0, 2000, 37):
+        ks = np.flatnonzero(cand[q])
+        d = np.abs(ux[ks] - uy[q]).sum(1)
+        order = np.lexsort((ks, d))[:2]
+        want_i = [int(ks[o]) for o in order] + [np.iinfo(np.uint64).max] * (2 - len(order))
+        want_d = [float(d[o]) for o in order] + [2147483648.0] * (2 - len(order))
+        assert idx[q].tolist() == want_i and dist[q].tolist() == want_d
+
+
+def test_dlt_reference_test_properties(oracle):
+    """reference test/test_mvg.py:94-125 on randn cameras and points."""
+    rng = np.random.default_rng(0xdeadbeef)
+    for _ in range(100):
+        P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+        X0 = rng.standard_normal(4)
+        x, xp = P0 @ X0, P1 @ X0
+        err = oracle.dlt_reprojection_error(P0, P1, x, xp)
+        assert abs(err[0, 0]) < 1e-3
+        X = oracle.dlt_triangulate(P0, P1, x, xp)[0]
+        assert np.allclose(X / X[3], X0 / X0[3])
+        assert np.allclose(np.cross(P0 @ X, x), 0, atol=1e-8)
+        assert abs(np.linalg.norm(X) - 1) < 1e-12 and X[3] >= 0
+
+
+def test_dlt_matches_lapack_and_golden(oracle, golden):
+    g = golden("dlt_1000.npz")
+    X = oracle.dlt_triangulate(g["P0"], g["P1"], g["x"], g["xp"])
+    assert np.array_equal(X, g["X"])
+    assert np.max(np.abs(X - g["X_lapack"])) < 1e-9
+    err = oracle.dlt_reprojection_error(g["P0"], g["P1"], g["x"], g["xp"])
+    assert np.array_equal(err, g["err"])
+    assert np.all(err[:500] < 1e-9) and np.all(err[500:] < 1e-1)
+    assert np.all(oracle.dlt_cheirality(g["P0"], g["P1"], g["x"], g["xp"]))

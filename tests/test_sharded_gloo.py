@@ -1,0 +1,75 @@
+"""CPU-only: the query-sharding + gather path with world_size 2 over gloo.  The local
+compute is injected (the CPU oracle) because there is no GPU in this container; the HIP
+path is the default `local_fn` and is covered by the -m gpu tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_everything():
+    from spectavi_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 8, 1000, 4_000_000):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_pack_roundtrip():
+    from spectavi_amd.sharded import pack_records, unpack_records
+    idx = torch.tensor([[3, -1], [0, 2 ** 31 - 2]], dtype=torch.int64)
+    d = torch.tensor([[5, 2 ** 31 - 1], [0, 32640]], dtype=torch.int32)
+    i2, d2 = unpack_records(pack_records(idx, d))
+    assert torch.equal(i2, idx) and torch.equal(d2, d)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from spectavi_amd.sharded import nn_bruteforcel1k2_sharded, shard_bounds
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    y = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    lo, hi = shard_bounds(nq, world, rank)
+
+    def local_fn(xt, yt):
+        idx, d = o.nn_bruteforcel1k2(xt.numpy(), yt.numpy())
+        return torch.from_numpy(idx.view(np.int64)), torch.from_numpy(d)
+
+    idx, d = nn_bruteforcel1k2_sharded(torch.from_numpy(x), torch.from_numpy(y[lo:hi]), nq,
+                                       local_fn=local_fn)
+    if rank == 0:
+        want_i, want_d = o.nn_bruteforcel1k2(x, y)
+        ok = np.array_equal(idx.numpy().view(np.uint64), want_i) and np.array_equal(d.numpy(), want_d)
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    else:
+        assert idx is None and d is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gather_world2_gloo(tmp_path):
+    for nq in (101, 64):  # ragged and even shards
+        out = tmp_path / ("res%d.txt" % nq)
+        mp.spawn(_worker, args=(2, _free_port(), nq, str(out)), nprocs=2, join=True)
+        assert out.read_text() == "ok"
