@@ -57,9 +57,10 @@ const char *spv_version(void);
 void spv_profile_enable(int on);
 void spv_profile_reset(void);
 int spv_profile_read(const char *kernel, long long *launches, double *total_ms);
-/* Diagnostic: sustained v_sad_hi_u8 lane-ops/s with register operands only
- * (`blocks` workgroups of 256 lanes, `iters` x 64 SADs per lane). */
-int spv_microbench_sad(int blocks, int iters, double *lane_ops_per_s);
+/* Diagnostic: sustained issue rate of one VALU instruction with register
+ * operands only (op: 0 v_sad_hi_u8, 1 v_sad_u8, 2 v_sad_u16, 3 v_xor+v_add,
+ * 4 v_fma_f32, 5 v_dot4_u32_u8, 6 v_med3_u32) and the shader clock held. */
+int spv_microbench_valu(int op, int blocks, int iters, double *lane_ops_per_s, double *clock_ghz);
 
 /* ------------------------------------------------------------------------ */
 /* 1. Reference-compatible symbols (same names, argument order and meaning)  */

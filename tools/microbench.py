@@ -1,4 +1,4 @@
-"""Prints the sustained v_sad_hi_u8 rate of the attached GPU (roofline constant)."""
+"""Prints sustained VALU issue rates of the attached GPU (roofline constants for DESIGN.md)."""
 import ctypes as ct
 import os
 import sys
@@ -6,10 +6,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spectavi_amd._lib import clib, check  # noqa: E402
 
-clib.spv_microbench_sad.restype = ct.c_int
-clib.spv_microbench_sad.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_double)]
-for blocks in (256, 512, 1024, 2048, 4096):
-    r = ct.c_double(0)
-    check(clib.spv_microbench_sad(blocks, 20000, ct.byref(r)))
-    print("blocks=%5d  %.3f Tlane-op/s  (%.1f %% of 256 CU x 128 lanes x 2.4 GHz)" % (
-        blocks, r.value / 1e12, 100 * r.value / (256 * 128 * 2.4e9)))
+clib.spv_microbench_valu.restype = ct.c_int
+clib.spv_microbench_valu.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double)]
+NAMES = ["v_sad_hi_u8", "v_sad_u8", "v_sad_u16", "v_xor+v_add (2 ops)", "v_fma_f32", "v_dot4_u32_u8", "v_med3_u32"]
+for op, name in enumerate(NAMES):
+    for blocks in (256, 1024, 4096):
+        r, c = ct.c_double(0), ct.c_double(0)
+        check(clib.spv_microbench_valu(op, blocks, 20000, ct.byref(r), ct.byref(c)))
+        cyc = 256 * 4 * c.value * 1e9 / (r.value / 64.0)  # SIMD-cycles per wave64 instruction at that clock
+        print("%-20s blocks=%5d  %7.3f Tlane-op/s  clock %.2f GHz  %.2f cyc/wave-instr/SIMD" % (
+            name, blocks, r.value / 1e12, c.value, cyc))
