@@ -27,10 +27,13 @@ if ROOT not in sys.path:
 
 METRIC = "descriptor-pairs/sec, L1 2-NN, 128-D SIFT; achieved HBM GB/s vs roofline"
 
-# MI355X constants (/opt/skills/guides/MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32 = 128 VALU
-# lanes per CU per clock at 2.4 GHz; HBM3E 8 TB/s.
-CUS, LANES_PER_CU_CLK, CLK_HZ = 256, 128, 2.4e9
-VALU_LANE_OPS_PEAK = CUS * LANES_PER_CU_CLK * CLK_HZ
+# MI355X constants (/opt/skills/guides/MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, 2.4 GHz max clock,
+# HBM3E 8 TB/s.  v_sad_hi_u8 (like every 3-source VOP3 integer op measured: v_sad_u8/u16,
+# v_med3_u32, v_dot4_u32_u8) issues one wave64 instruction per 4 cycles per SIMD on gfx950
+# (tools/microbench.py: 4.13-4.19 cycles at saturation, profiles/r01_microbench.txt), i.e.
+# 16 lanes/clk/SIMD = 64 lanes/clk/CU.  Peak = 256 x 64 x 2.4e9 = 3.93e13 SAD lane-ops/s.
+CUS, SAD_LANES_PER_CU_CLK, CLK_HZ = 256, 64, 2.4e9
+VALU_LANE_OPS_PEAK = CUS * SAD_LANES_PER_CU_CLK * CLK_HZ
 HBM_PEAK_GBS = 8000.0
 
 
@@ -158,7 +161,8 @@ def main():
         compulsory = (args.xrows + args.yrows) * args.dim + 24 * args.yrows
         roofline = {
             # Sum-of-absolute-differences is not a contraction, so neither MFMA nor HBM bounds
-            # this kernel: the binding unit is the integer VALU (v_sad_hi_u8, 4 bytes/lane-op).
+            # this kernel: the binding unit is the integer VALU's v_sad issue rate (4 bytes/lane-op,
+            # one wave64 instruction per 4 cycles per SIMD at the nominal 2.4 GHz).
             "bound": "valu",
             "kernel": "l1k2_tile_kernel",
             "achieved": kpairs * groups / 1e12,

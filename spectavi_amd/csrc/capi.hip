@@ -419,8 +419,9 @@ int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, cons
 
 // ---- device-pointer variants --------------------------------------------------------
 size_t spv_l1k2_workspace_bytes(int xrows, int yrows, int dim) {
-  if (dim <= 0 || dim % 16 != 0 || dim > 256 || xrows < 0 || yrows < 0) return 0;
-  return l1k2_plan(xrows, yrows, dim).total_bytes;
+  if (dim <= 0 || dim % 16 != 0 || xrows < 0 || yrows < 0) return 0;
+  const L1K2Plan p = l1k2_plan(xrows, yrows, dim);
+  return p.dim_pad < 0 ? 0 : p.total_bytes;
 }
 
 int spv_l1k2_device(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int dim,

@@ -46,6 +46,7 @@ constexpr int kThreads = 256;
 constexpr int kTileRows = 64;               // database rows per LDS tile
 constexpr uint32_t kKeyNone = 0xFFFFFFFFu;  // > any real key (dist <= 65280)
 constexpr uint64_t kKey64None = ~0ull;
+constexpr int kMaxGenericDim = 2048;        // generic fallback: 64 queries x dim bytes of LDS
 
 __device__ __forceinline__ uint32_t sad_hi(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_sad_hi_u8(a, b, c);  // (SAD_U8(a,b) << 16) + c
@@ -82,8 +83,17 @@ __device__ __forceinline__ void row_update(const uint32_t (&qreg)[Q][D4], const 
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][4 * c + 3], xr[c].w, acc[q]);
   }
+  // Lazy top-2: a new key enters only if it beats the current second best of
+  // its query.  After the first few hundred rows of a slice that is rare, so the
+  // common case is Q compares and one wave-uniform branch instead of Q x
+  // (v_min + v_med3).  Result-identical to the eager update.
+  bool any = false;
 #pragma unroll
-  for (int q = 0; q < Q; ++q) top2_insert(k1[q], k2[q], acc[q]);
+  for (int q = 0; q < Q; ++q) any |= acc[q] < k2[q];
+  if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) top2_insert(k1[q], k2[q], acc[q]);
+  }
 }
 
 // Partial-key layout: part[(query * S + slice) * 2 + {0,1}], key = dist<<32 | global idx.
@@ -274,6 +284,49 @@ __global__ __launch_bounds__(kThreads, 2) void l1k2_tile_kernel_sfeed(
 }
 
 // ---------------------------------------------------------------------------------
+// Generic-width fallback (256 < dim <= 2048): one wave per 64 queries, the queries live
+// transposed in LDS ([dim/4][64] dwords, conflict-free per-lane reads), database rows
+// arrive through wave-uniform scalar loads, 32-bit distance, 64-bit keys.  Correctness
+// path for unusual descriptor widths; the tuned kernels above cover dim <= 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void l1k2_generic_kernel(const uint32_t *__restrict__ x,
+                                                          const uint32_t *__restrict__ y, int M,
+                                                          int N, int D4, int slice_rows, int S,
+                                                          uint64_t *__restrict__ part) {
+  extern __shared__ uint32_t lq[];  // [D4][64]
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x * 64 + lane;
+  const int src = min(qi, N - 1);
+  for (int i = 0; i < D4; ++i) lq[i * 64 + lane] = y[(size_t)src * D4 + i];
+  const int s = blockIdx.y;
+  const int row_begin = s * slice_rows;
+  const int row_end = min(M, row_begin + slice_rows);
+  uint64_t k1 = kKey64None, k2 = kKey64None;
+  for (int r = row_begin; r < row_end; ++r) {
+    const uint32_t *xr = x + (size_t)r * D4;  // wave-uniform
+    uint32_t acc = 0;
+    for (int i = 0; i < D4; i += 4) {
+      acc = __builtin_amdgcn_sad_u8(lq[(i + 0) * 64 + lane], xr[i + 0], acc);
+      acc = __builtin_amdgcn_sad_u8(lq[(i + 1) * 64 + lane], xr[i + 1], acc);
+      acc = __builtin_amdgcn_sad_u8(lq[(i + 2) * 64 + lane], xr[i + 2], acc);
+      acc = __builtin_amdgcn_sad_u8(lq[(i + 3) * 64 + lane], xr[i + 3], acc);
+    }
+    const uint64_t k = ((uint64_t)acc << 32) | (uint32_t)r;
+    if (k < k1) {
+      k2 = k1;
+      k1 = k;
+    } else if (k < k2) {
+      k2 = k;
+    }
+  }
+  if (qi < N) {
+    uint64_t *dst = part + ((size_t)qi * S + s) * 2;
+    dst[0] = k1;
+    dst[1] = k2;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Merge kernel: LPQ lanes per query stride over the S partial pairs, then an
 // argmin-2 butterfly over those lanes (wavefront shuffles).
 // ---------------------------------------------------------------------------------
@@ -369,7 +422,7 @@ void launch_tile(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Pla
 template <int D4>
 void launch_tile_q(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Plan &p,
                    uint64_t *part, hipStream_t stream) {
-  constexpr int QMAX = D4 <= 32 ? 4 : (D4 <= 48 ? 2 : 1);
+  constexpr int QMAX = D4 <= 16 ? 4 : (D4 <= 36 ? 2 : 1);
   if (p.q >= 4 && QMAX >= 4)
     launch_tile<D4, (QMAX >= 4 ? 4 : 1)>(x, y, M, N, p, part, stream);
   else if (p.q >= 2 && QMAX >= 2)
@@ -378,7 +431,9 @@ void launch_tile_q(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2P
     launch_tile<D4, 1>(x, y, M, N, p, part, stream);
 }
 
-int max_q_for(int dim_pad) { return dim_pad <= 128 ? 4 : (dim_pad <= 192 ? 2 : 1); }
+// Queries per lane.  Measured on MI355X at 256k x 256k, D=128 (tools/l1k2_sweep.py): Q=2
+// (154 VGPRs, 3 waves/SIMD) beats Q=4 (224 VGPRs, 2 waves/SIMD) by ~3 % and Q=1 by ~15 %.
+int max_q_for(int dim_pad) { return dim_pad <= 64 ? 4 : (dim_pad <= 144 ? 2 : 1); }
 
 }  // namespace
 
@@ -387,25 +442,34 @@ static int pick_dim_pad(int dim) {
   static const int kDims[] = {64, 128, 144, 192, 256};
   for (int d : kDims)
     if (dim <= d) return d;
-  return -1;
+  return dim <= kMaxGenericDim ? dim : -1;  // generic fallback kernel, no padding
 }
 
 L1K2Plan l1k2_plan(int xrows, int yrows, int dim) {
   L1K2Plan p{};
   p.dim_pad = pick_dim_pad(dim);
   if (p.dim_pad < 0 || xrows < 0 || yrows < 0) return p;
-  const int qmax = max_q_for(p.dim_pad);
+  const bool generic = p.dim_pad > 256;
+  const int qmax = generic ? 1 : max_q_for(p.dim_pad);
+  const int qlanes = generic ? 64 : kThreads;  // queries per workgroup per unit of q
   // queries per lane: as many as registers allow once there are enough queries
   // to keep >= 512 workgroups of 256 lanes busy without it
-  int q = 1;
-  while (q * 2 <= qmax && (long long)yrows >= 512LL * kThreads * (q * 2) / 4) q *= 2;
+  // as many queries per lane as registers allow, unless that leaves too few workgroups
+  // (query blocks x possible database slices) to fill the chip
+  int q = qmax;
+  while (q > 1) {
+    const long long qb = ((long long)yrows + qlanes * q - 1) / (qlanes * q);
+    const long long smax = std::max<long long>(1, xrows / kTileRows);
+    if (qb * smax >= 1024) break;
+    q /= 2;
+  }
   static const int q_env = env_int("SPECTAVI_L1K2_Q", 0);
   if (q_env == 1 || q_env == 2 || q_env == 4) q = std::min(q_env, qmax);
   p.q = q;
-  p.qblocks = std::max(1, (yrows + kThreads * q - 1) / (kThreads * q));
+  p.qblocks = std::max(1, (yrows + qlanes * q - 1) / (qlanes * q));
   // database slices: enough workgroups to fill 256 CUs x 2 several times over,
   // each slice a multiple of the tile and <= 65536 rows (16-bit local index)
-  static const int want_blocks = std::max(1, env_int("SPECTAVI_L1K2_BLOCKS", 2048));
+  static const int want_blocks = std::max(1, env_int("SPECTAVI_L1K2_BLOCKS", 4096));
   int s_target = std::max(1, (want_blocks + p.qblocks - 1) / p.qblocks);
   long long rows = (xrows + s_target - 1) / s_target;
   rows = (rows + kTileRows - 1) / kTileRows * kTileRows;
@@ -427,8 +491,9 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
   if (dim <= 0 || dim % 16 != 0)
     return set_error(SPV_ERR_INVALID,
                      "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
-  if (dim > 256)
-    return set_error(SPV_ERR_INVALID, "dim=%d > 256 is not supported by the gfx950 L1 kernel", dim);
+  if (dim > kMaxGenericDim)
+    return set_error(SPV_ERR_INVALID, "dim=%d > %d is not supported by the gfx950 L1 kernels", dim,
+                     kMaxGenericDim);
   if (yrows == 0) return SPV_OK;
   if (!d_y || !d_idx || !d_dist || (xrows > 0 && !d_x))
     return set_error(SPV_ERR_INVALID, "null device pointer");
@@ -459,7 +524,17 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
     case 144: launch_tile_q<36>(kx, ky, xrows, yrows, p, part, stream); break;
     case 192: launch_tile_q<48>(kx, ky, xrows, yrows, p, part, stream); break;
     case 256: launch_tile_q<64>(kx, ky, xrows, yrows, p, part, stream); break;
-    default: return set_error(SPV_ERR_INVALID, "internal: bad dim_pad %d", p.dim_pad);
+    default: {
+      if (p.dim_pad <= 256 || p.dim_pad > kMaxGenericDim)
+        return set_error(SPV_ERR_INVALID, "internal: bad dim_pad %d", p.dim_pad);
+      const size_t lds = (size_t)64 * p.dim_pad;
+      SPV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(l1k2_generic_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(l1k2_generic_kernel, dim3(p.qblocks, p.slices), dim3(64), lds, stream,
+                         reinterpret_cast<const uint32_t *>(kx),
+                         reinterpret_cast<const uint32_t *>(ky), xrows, yrows, p.dim_pad / 4,
+                         p.slice_rows, p.slices, part);
+    }
   }
   }
   SPV_HIP_CHECK(hipGetLastError());
