@@ -101,10 +101,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # Rehearsal on a 1-GPU box (SPECTAVI_BENCH_REHEARSE=1): every rank shares cuda:0 and the
+    # gather runs over gloo on host copies.  It exercises the sharding / gather / timing code;
+    # its numbers are not benchmark results (printed with "rehearsal": true).
+    rehearse = os.environ.get("SPECTAVI_BENCH_REHEARSE", "") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from spectavi_amd import device as spv
     from spectavi_amd.sharded import pack_records
@@ -116,13 +125,15 @@ def main():
     gy = torch.Generator(device=dev).manual_seed(0xdeadbeef + 1 + rank)
     y = torch.randint(0, 256, (args.yrows, args.dim), dtype=torch.uint8, device=dev, generator=gy)
     gather_bufs = None
+    gdev = torch.device("cpu") if rehearse else dev
     if world > 1 and rank == 0:
-        gather_bufs = [torch.empty((args.yrows, 4), dtype=torch.int32, device=dev) for _ in range(world)]
+        gather_bufs = [torch.empty((args.yrows, 4), dtype=torch.int32, device=gdev) for _ in range(world)]
 
     def step():
         idx, d = spv.l1k2(x, y)
         if world > 1:
-            dist.gather(pack_records(idx, d), gather_list=gather_bufs, dst=0)
+            rec = pack_records(idx, d)
+            dist.gather(rec.cpu() if rehearse else rec, gather_list=gather_bufs, dst=0)
         return idx, d
 
     def fence():
@@ -145,7 +156,7 @@ def main():
     launches, tile_ms = spv.profile_read("l1k2_tile")
     _, merge_ms = spv.profile_read("l1k2_merge")
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -202,6 +213,12 @@ def main():
                        "parallelism": "query-shard x%d, database replicated, RCCL gather of 16 B records" % world},
             "roofline": roofline, "cpu_baseline": cpu, "verified_vs_oracle": verified,
         }
+        if world > 1:
+            # shard 0 of the gathered records must be rank 0's own result
+            i0, d0 = gather_bufs[0][:, 0:2].to(dev), gather_bufs[0][:, 2:4].to(dev)
+            out["gather_consistent"] = bool(torch.equal(i0, idx.to(torch.int32)) and torch.equal(d0, d))
+        if rehearse:
+            out["rehearsal"] = True
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -133,6 +133,16 @@ int spv_generate_hash_dict(uint32_t seed, int dim, int m, int n, float *dict);
 /* Fix (use_fixed != 0) or release the seed used by nn_cascading_hash. */
 void spv_set_hash_seed(uint32_t seed, int use_fixed);
 
+/* RANSAC hypothesis scoring (the inner loops of reference src/RansacFitter.h:59-95):
+ * for each of nhyp candidate second cameras P1s[h] (double[nhyp,3,4]) triangulate all npt
+ * correspondences against P0 and count the inliers, i.e. points with
+ * reprojection_error() <= max_error that are in front of both cameras
+ * (src/DltTriangulator.h:67-86).  counts: int32[nhyp]; mask (may be NULL):
+ * uint8[nhyp, npt], 1 = inlier. */
+int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
+                             const double *x, const double *xp, double max_error,
+                             int32_t *counts, uint8_t *mask);
+
 int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                         const double *xp, double *dst);
 int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
@@ -169,6 +179,13 @@ int spv_dlt_triangulate_device(const double *P0, const double *P1, long long npt
 int spv_dlt_reprojection_error_device(const double *P0, const double *P1, long long npt,
                                       const double *d_x, const double *d_xp, double *d_dst,
                                       void *stream);
+
+/* Device form of spv_dlt_score_hypotheses: P0 is a HOST pointer (12 doubles), d_P1s
+ * double[nhyp,12], d_counts int32[nhyp] (zeroed by the call), d_mask uint8[nhyp,npt] or NULL. */
+int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,
+                                    long long npt, const double *d_x, const double *d_xp,
+                                    double max_error, int32_t *d_counts, uint8_t *d_mask,
+                                    void *stream);
 
 #ifdef __cplusplus
 }

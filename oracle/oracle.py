@@ -55,6 +55,8 @@ def lib():
             fn.argtypes = [f64, f64, ct.c_int, f64, f64, f64]
         L.oracle_dlt_cheirality.restype = None
         L.oracle_dlt_cheirality.argtypes = [f64, f64, ct.c_int, f64, f64, u8]
+        L.oracle_dlt_score_hypotheses.restype = None
+        L.oracle_dlt_score_hypotheses.argtypes = [f64, f64, ct.c_int, ct.c_int, f64, f64, ct.c_double, i32, u8]
         L.oracle_max_threads.restype = ct.c_int
         _lib = L
     return _lib
@@ -137,6 +139,17 @@ def dlt_cheirality(P0, P1, x, xp):
     out = np.empty(x.shape[0], np.uint8)
     lib().oracle_dlt_cheirality(P0, P1, x.shape[0], x, xp, out)
     return out.astype(bool)
+
+
+def dlt_score_hypotheses(P0, P1s, x, xp, max_error):
+    """(counts int32[H], mask bool[H,npt]) -- restates reference src/RansacFitter.h:59-95."""
+    P1s = np.ascontiguousarray(P1s, dtype=np.float64).reshape(-1, 3, 4)
+    P0, _, x, xp = _dlt_args(P0, P1s[0] if len(P1s) else np.zeros((3, 4)), x, xp)
+    counts = np.zeros(P1s.shape[0], np.int32)
+    mask = np.zeros((P1s.shape[0], x.shape[0]), np.uint8)
+    lib().oracle_dlt_score_hypotheses(P0, P1s.reshape(-1, 12), P1s.shape[0], x.shape[0], x, xp,
+                                      float(max_error), counts, mask.reshape(-1))
+    return counts, mask.astype(bool)
 
 
 # ----------------------------------------------------------------------------------

@@ -175,4 +175,35 @@ void oracle_dlt_cheirality(const double *P0, const double *P1, int npt, const do
   }
 }
 
+// RANSAC hypothesis scoring: counts int32[nhyp], mask uint8[nhyp,npt] (may be NULL).
+// Restates the two scoring loops of reference src/RansacFitter.h:59-73 and :86-94
+// (inlier iff reprojection_error() <= max_error && is_infront_both_cameras()).
+void oracle_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
+                                 const double *x, const double *xp, double max_error,
+                                 int32_t *counts, uint8_t *mask) {
+  for (int h = 0; h < nhyp; ++h) {
+    const double *P1 = P1s + 12 * (size_t)h;
+    const double s0 = det3(P0) < 0 ? -1.0 : 1.0, s1 = det3(P1) < 0 ? -1.0 : 1.0;
+    const double n0 = P0[2] * P0[2] + P0[6] * P0[6] + P0[10] * P0[10];
+    const double n1 = P1[2] * P1[2] + P1[6] * P1[6] + P1[10] * P1[10];
+    int cnt = 0;
+    for (int i = 0; i < npt; ++i) {
+      Solve s;
+      dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
+      double r0[3], r1[3];
+      reproject(P0, s.X, r0);
+      reproject(P1, s.X, r1);
+      const double e0x = r0[0] / r0[2] - s.u, e0y = r0[1] / r0[2] - s.v;
+      const double e1x = r1[0] / r1[2] - s.up, e1y = r1[1] / r1[2] - s.vp;
+      const double err = std::sqrt(e0x * e0x + e0y * e0y) + std::sqrt(e1x * e1x + e1y * e1y);
+      const double dc0 = s0 / n0 * r0[2] / s.X[3];
+      const double dc1 = s1 / n1 * r1[2] / s.X[3];
+      const bool in = (err <= max_error) && (dc0 > 0) && (dc1 > 0);
+      cnt += in ? 1 : 0;
+      if (mask) mask[(size_t)h * npt + i] = in ? 1 : 0;
+    }
+    counts[h] = cnt;
+  }
+}
+
 }  // extern "C"

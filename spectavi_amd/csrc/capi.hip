@@ -220,6 +220,34 @@ int host_dlt(const double *P0, const double *P1, int npt, const double *x, const
   return SPV_OK;
 }
 
+int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const double *x,
+                   const double *xp, double max_error, int32_t *counts, uint8_t *mask) {
+  if (npt < 0 || nhyp < 0) return set_error(SPV_ERR_INVALID, "negative count");
+  if (nhyp == 0) return SPV_OK;
+  if (!P0 || !P1s || !counts || (npt > 0 && (!x || !xp))) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  const size_t ib = (size_t)npt * 3 * sizeof(double);
+  DevBuf dx, dxp, dp, dc, dm;
+  SPV_TRY(dx.alloc(ib));
+  SPV_TRY(dxp.alloc(ib));
+  SPV_TRY(dp.alloc((size_t)nhyp * 12 * sizeof(double)));
+  SPV_TRY(dc.alloc((size_t)nhyp * sizeof(int32_t)));
+  if (mask) SPV_TRY(dm.alloc((size_t)nhyp * npt));
+  hipStream_t st = nullptr;
+  if (ib) {
+    SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, xp, ib, hipMemcpyHostToDevice, st));
+  }
+  SPV_HIP_CHECK(hipMemcpyAsync(dp.p, P1s, (size_t)nhyp * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+  SPV_TRY(dlt_score_run(P0, dp.as<double>(), nhyp, npt, dx.as<double>(), dxp.as<double>(), max_error,
+                        dc.as<int>(), mask ? dm.as<unsigned char>() : nullptr, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(counts, dc.p, (size_t)nhyp * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (mask && npt > 0)
+    SPV_HIP_CHECK(hipMemcpyAsync(mask, dm.p, (size_t)nhyp * npt, hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
 // Hyperplanes as the reference draws them (src/CascadingHashNn.h:86-100):
 // one std::mt19937 stream, std::normal_distribution<float>(0,1), table-major,
 // then dim (i), then bit (j).
@@ -410,6 +438,20 @@ int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const doubl
                         const double *xp, double *dst) {
   clear_error();
   return host_dlt(P0, P1, npt, x, xp, dst, false);
+}
+int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
+                             const double *x, const double *xp, double max_error,
+                             int32_t *counts, uint8_t *mask) {
+  clear_error();
+  return host_dlt_score(P0, P1s, nhyp, npt, x, xp, max_error, counts, mask);
+}
+int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,
+                                    long long npt, const double *d_x, const double *d_xp,
+                                    double max_error, int32_t *d_counts, uint8_t *d_mask,
+                                    void *stream) {
+  clear_error();
+  return dlt_score_run(P0, d_P1s, nhyp, npt, d_x, d_xp, max_error, d_counts, d_mask,
+                       static_cast<hipStream_t>(stream));
 }
 int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                                const double *xp, double *dst) {

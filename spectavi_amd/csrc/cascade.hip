@@ -301,33 +301,53 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
   int visited = 0;
 
   auto refine = [&](int count) {
-    // `count` candidate indices in list[0..count): 8 per round, one per lane group
-    for (int c0 = 0; c0 < count; c0 += 8) {
-      const int ci = c0 + grp;
-      const bool live = ci < count;
-      const uint32_t cand = list[live ? ci : 0];
-      uint32_t d = 0;
+    // `count` candidate indices in list[0..count).  Each 8-lane group takes one candidate
+    // per round (8 rows = 8 full 128-byte lines per wave instruction); four rounds of row
+    // gathers are issued before the first is consumed so the random-row latency overlaps.
+    constexpr int RU = 4;
+    for (int c0 = 0; c0 < count; c0 += 8 * RU) {
+      uint4 xv[RU][CPL];
+      uint32_t cand[RU];
+      bool live[RU];
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int ch = sub + 8 * c;
-        if (ch < nchunk) {
-          const uint4 xv = *reinterpret_cast<const uint4 *>(ux + (size_t)cand * dim + 16 * ch);
-          d = sad_u8(qv[c].x, xv.x, d);
-          d = sad_u8(qv[c].y, xv.y, d);
-          d = sad_u8(qv[c].z, xv.z, d);
-          d = sad_u8(qv[c].w, xv.w, d);
+      for (int u = 0; u < RU; ++u) {
+        const int ci = c0 + 8 * u + grp;
+        live[u] = ci < count;
+        cand[u] = list[live[u] ? ci : 0];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int ch = sub + 8 * c;
+          xv[u][c] = make_uint4(0, 0, 0, 0);
+          if (live[u] && ch < nchunk)
+            xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)cand[u] * dim + 16 * ch);
         }
       }
-      d = group8_sum(d);
-      if (live) top2_insert_distinct(k1, k2, ((uint64_t)d << 32) | cand);
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          d = sad_u8(qv[c].x, xv[u][c].x, d);
+          d = sad_u8(qv[c].y, xv[u][c].y, d);
+          d = sad_u8(qv[c].z, xv[u][c].z, d);
+          d = sad_u8(qv[c].w, xv[u][c].w, d);
+        }
+        d = group8_sum(d);
+        if (live[u]) top2_insert_distinct(k1, k2, ((uint64_t)d << 32) | cand[u]);
+      }
     }
   };
 
   const int nvar = 1 << g;
   const int nprobe = n * nvar;
-  for (int p0 = 0; p0 < nprobe; p0 += 64) {
-    // one probe per lane: bucket range
-    const int p = p0 + lane;
+  // lanes per probe: with few probes (n * 2^g = 8 by default) several lanes share one
+  // bucket and copy it cooperatively
+  int lpp = 1;
+  while (lpp * 2 * nprobe <= 64) lpp *= 2;
+  const int ppc = 64 / lpp;  // probes per pass of the wave
+  for (int p0 = 0; p0 < nprobe; p0 += ppc) {
+    const int p = p0 + lane / lpp;
+    const int psub = lane % lpp;
     uint32_t s = 0, len = 0, pcode = 0;
     int tj = 0;
     if (p < nprobe) {
@@ -340,8 +360,9 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
       s = bs[0];
       len = bs[1] - s;
     }
-    // wave-wide totals
-    uint32_t incl = len;
+    // exclusive offsets of the buckets in the list: scan over the first lane of each probe
+    const uint32_t mylen = psub == 0 ? len : 0u;
+    uint32_t incl = mylen;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t o = __shfl_up(incl, d, 64);
@@ -349,22 +370,22 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     }
     const uint32_t total = __shfl(incl, 63, 64);
     if (!check_code && total <= (uint32_t)kListCap) {
-      // fast path: every lane copies its own bucket into the shared list
-      uint32_t dst = incl - len;
+      // fast path: the lanes of a probe copy its bucket into the shared list
+      const uint32_t dst = __shfl(incl - mylen, lane - psub, 64);
       const uint32_t *src = order + (size_t)tj * M + s;
-      for (uint32_t i = 0; i < len; ++i) list[dst + i] = src[i];
+      for (uint32_t i = psub; i < len; i += lpp) list[dst + i] = src[i];
       __builtin_amdgcn_wave_barrier();
       refine((int)total);
       visited += (int)total;
       __builtin_amdgcn_wave_barrier();
     } else {
       // general path: buckets one at a time, 64 entries per step, optional full-code check
-      const int np = min(64, nprobe - p0);
+      const int np = min(ppc, nprobe - p0);
       for (int pp = 0; pp < np; ++pp) {
-        const uint32_t ps = __shfl(s, pp, 64);
-        const uint32_t pl = __shfl(len, pp, 64);
-        const uint32_t pc = __shfl(pcode, pp, 64);
-        const int pj = __shfl(tj, pp, 64);
+        const uint32_t ps = __shfl(s, pp * lpp, 64);
+        const uint32_t pl = __shfl(len, pp * lpp, 64);
+        const uint32_t pc = __shfl(pcode, pp * lpp, 64);
+        const int pj = __shfl(tj, pp * lpp, 64);
         for (uint32_t off = 0; off < pl; off += 64) {
           const uint32_t e = off + lane;
           bool keep = e < pl;

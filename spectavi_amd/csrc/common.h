@@ -62,4 +62,8 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
 int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x,
             const double *d_xp, double *d_dst, bool want_error, hipStream_t stream);
 
+int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
+                  const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,
+                  hipStream_t stream);
+
 }  // namespace spv

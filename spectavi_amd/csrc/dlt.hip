@@ -168,7 +168,96 @@ __global__ __launch_bounds__(kDltThreads) void dlt_kernel(Cameras cam, long long
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// RANSAC hypothesis scoring: the reference scores every
+// candidate second camera by triangulating ALL correspondences and counting
+// those with reprojection error <= threshold that lie in front of both cameras
+// (src/RansacFitter.h:59-73, src/DltTriangulator.h:67-86).  grid = (point
+// blocks, hypotheses); one lane = one (point, hypothesis); per-wave ballot
+// counts feed one atomicAdd per wave.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double det3_left(const double *P) {
+  return P[0] * (P[5] * P[10] - P[6] * P[9]) - P[1] * (P[4] * P[10] - P[6] * P[8]) +
+         P[2] * (P[4] * P[9] - P[5] * P[8]);
+}
+
+__global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
+    Cameras cam0, const double *__restrict__ p1s, long long npt, const double *__restrict__ x,
+    const double *__restrict__ xp, double max_error, int *__restrict__ counts,
+    unsigned char *__restrict__ mask) {
+  __shared__ double sx[kDltThreads * 3];
+  __shared__ double sxp[kDltThreads * 3];
+  const int h = blockIdx.y;
+  Cameras cam;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    cam.p0[i] = cam0.p0[i];
+    cam.p1[i] = p1s[(size_t)h * 12 + i];  // wave-uniform
+  }
+  const long long base = (long long)blockIdx.x * kDltThreads;
+  const long long nblk = min((long long)kDltThreads, npt - base);
+  for (int e = threadIdx.x; e < nblk * 3; e += kDltThreads) {
+    sx[e] = x[base * 3 + e];
+    sxp[e] = xp[base * 3 + e];
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  bool inlier = false;
+  if (t < nblk) {
+    double X[4], u, v, up, vp;
+    dlt_solve(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1],
+              sxp[3 * t + 2], X, u, v, up, vp);
+    double r0[3], r1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a += cam.p0[4 * r + c] * X[c];
+        b += cam.p1[4 * r + c] * X[c];
+      }
+      r0[r] = a;
+      r1[r] = b;
+    }
+    const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
+    const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
+    const double err = sqrt(e0x * e0x + e0y * e0y) + sqrt(e1x * e1x + e1y * e1y);
+    const double s0 = det3_left(cam.p0) < 0 ? -1.0 : 1.0, s1 = det3_left(cam.p1) < 0 ? -1.0 : 1.0;
+    const double n0 = cam.p0[2] * cam.p0[2] + cam.p0[6] * cam.p0[6] + cam.p0[10] * cam.p0[10];
+    const double n1 = cam.p1[2] * cam.p1[2] + cam.p1[6] * cam.p1[6] + cam.p1[10] * cam.p1[10];
+    const double dc0 = s0 / n0 * r0[2] / X[3];
+    const double dc1 = s1 / n1 * r1[2] / X[3];
+    inlier = (err <= max_error) && (dc0 > 0) && (dc1 > 0);
+    if (mask) mask[(size_t)h * npt + base + t] = inlier ? 1 : 0;
+  }
+  const unsigned long long bal = __ballot(inlier);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[h], __popcll(bal));
+}
+
 }  // namespace
+
+int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
+                  const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,
+                  hipStream_t stream) {
+  if (npt < 0 || nhyp < 0) return set_error(SPV_ERR_INVALID, "negative count");
+  if (!P0) return set_error(SPV_ERR_INVALID, "null camera pointer");
+  if (nhyp == 0) return SPV_OK;
+  if (!d_counts || !d_p1s) return set_error(SPV_ERR_INVALID, "null device pointer");
+  SPV_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)nhyp * sizeof(int), stream));
+  if (npt == 0) return SPV_OK;
+  if (!d_x || !d_xp) return set_error(SPV_ERR_INVALID, "null device pointer");
+  if (nhyp > 65535) return set_error(SPV_ERR_INVALID, "more than 65535 hypotheses per call");
+  Cameras cam0;
+  for (int i = 0; i < 12; ++i) cam0.p0[i] = cam0.p1[i] = P0[i];
+  const long long blocks = (npt + kDltThreads - 1) / kDltThreads;
+  if (blocks > 0x7FFFFFFFLL) return set_error(SPV_ERR_INVALID, "too many points");
+  ProfScope prof("dlt_score", stream);
+  hipLaunchKernelGGL(dlt_score_kernel, dim3((unsigned)blocks, (unsigned)nhyp), dim3(kDltThreads), 0,
+                     stream, cam0, d_p1s, npt, d_x, d_xp, max_error, d_counts, d_mask);
+  SPV_HIP_CHECK(hipGetLastError());
+  return SPV_OK;
+}
 
 int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x,
             const double *d_xp, double *d_dst, bool want_error, hipStream_t stream) {

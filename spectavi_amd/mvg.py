@@ -66,3 +66,46 @@ def dlt_triangulate(P0, P1, x, xp, ret_error=False):
 
 def dlt_reprojection_error(P0, P1, x, xp):
     return dlt_triangulate(P0, P1, x, xp, ret_error=True)
+
+
+# ==================================================================================
+# RANSAC hypothesis scoring (the inner loops of reference src/RansacFitter.h:59-95)
+# ==================================================================================
+_spv_dlt_score_hypotheses = clib.spv_dlt_score_hypotheses
+_spv_dlt_score_hypotheses.restype = ct.c_int
+_spv_dlt_score_hypotheses.argtypes = [ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                                      ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                                      ct.c_int, ct.c_int,
+                                      ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                                      ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                                      ct.c_double,
+                                      ndpointer(ct.c_int32, flags="C_CONTIGUOUS"),
+                                      ct.c_void_p]
+
+
+def dlt_score_hypotheses(P0, P1s, x, xp, max_error, return_mask=False):
+    """
+    Score candidate second cameras the way the reference's RANSAC does
+    (reference src/RansacFitter.h:59-73): for every camera P1s[h] triangulate all
+    correspondences against P0 and count the points whose reprojection error is
+    <= `max_error` and which lie in front of both cameras.
+
+    P0 float64 [3,4]; P1s float64 [H,3,4]; x, xp float64 [npt,3].
+    Returns counts int32 [H] (and the inlier mask bool [H,npt] with `return_mask`).
+    """
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    P1s = np.ascontiguousarray(P1s, dtype=np.float64)
+    if P1s.ndim == 2:
+        P1s = P1s[None]
+    if not (P0.shape == (3, 4) and P1s.shape[1:] == (3, 4)):
+        raise TypeError('P0,P1s must be camera matrices.')
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    xp = np.ascontiguousarray(xp, dtype=np.float64)
+    if not (x.ndim == 2 and xp.ndim == 2 and x.shape == xp.shape and x.shape[1] == 3):
+        raise TypeError('Coords must be homogenous [npt,3] pairs.')
+    nhyp, npt = P1s.shape[0], x.shape[0]
+    counts = np.zeros(nhyp, np.int32)
+    mask = np.zeros((nhyp, npt), np.uint8) if return_mask else None
+    check(_spv_dlt_score_hypotheses(P0, P1s.reshape(-1), nhyp, npt, x, xp, float(max_error), counts,
+                                    mask.ctypes.data if return_mask else None))
+    return (counts, mask.astype(bool)) if return_mask else counts

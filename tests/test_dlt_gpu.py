@@ -74,3 +74,45 @@ def test_device_path_10m_properties():
     assert float(err.max()) < 1e-8
     assert float((X / X[:, 3:4] - Xw).abs().max()) < 1e-6
     assert float(((X * X).sum(1) - 1).abs().max()) < 1e-12
+
+
+def _essential_cameras(rng):
+    """Four candidate second cameras of an essential matrix (the set the reference scores,
+    src/Camera.h:31-46), built directly from a random rotation and baseline."""
+    R, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(R) < 0:
+        R = -R
+    t = rng.standard_normal(3)
+    t /= np.linalg.norm(t)
+    W, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(W) < 0:
+        W = -W
+    return [np.hstack([R, t[:, None]]), np.hstack([R, -t[:, None]]),
+            np.hstack([W @ R, t[:, None]]), np.hstack([W @ R, -t[:, None]])]
+
+
+def test_score_hypotheses_matches_oracle(oracle):
+    """RANSAC scoring (reference src/RansacFitter.h:59-95): counts and masks bit-equal to the
+    oracle; the true camera wins."""
+    from spectavi_amd import mvg
+    rng = np.random.default_rng(12)
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    cams = _essential_cameras(rng)
+    npt = 5003
+    Xw = np.hstack([rng.standard_normal((npt, 2)), rng.uniform(4, 8, (npt, 1)), np.ones((npt, 1))])
+    x = Xw @ P0.T
+    xp = Xw @ cams[0].T
+    x[:, :2] += rng.normal(0, 2e-3, (npt, 2)) * x[:, 2:3]
+    xp[:, :2] += rng.normal(0, 2e-3, (npt, 2)) * xp[:, 2:3]
+    xp[::7] = rng.standard_normal((len(xp[::7]), 3))          # outliers
+    P1s = np.stack(cams + [rng.standard_normal((3, 4)) for _ in range(3)])
+    counts, mask = mvg.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2, return_mask=True)
+    ocounts, omask = oracle.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2)
+    assert np.array_equal(mask, omask)
+    assert np.array_equal(counts, ocounts) and np.array_equal(counts, mask.sum(1))
+    assert counts.argmax() == 0 and counts[0] > 0.8 * npt * 6 / 7
+    assert np.array_equal(mvg.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2), counts)
+    # the inlier definition, recomputed from the exported pieces
+    err = mvg.dlt_reprojection_error(P0, P1s[0], x, xp)[:, 0]
+    front = oracle.dlt_cheirality(P0, P1s[0], x, xp)
+    assert np.array_equal(mask[0], (err <= 1e-2) & front)
