@@ -180,6 +180,22 @@ int spv_dlt_reprojection_error_device(const double *P0, const double *P1, long l
                                       const double *d_x, const double *d_xp, double *d_dst,
                                       void *stream);
 
+/* Ratio test + ordered match compaction, the step right after the NN path in the
+ * reference's pipeline (example/ex01_essential_estimation.py:102-106): query q passes iff
+ * it has a nearest neighbour and (double)dist[q,1] / (double)dist[q,0] >= min_ratio under
+ * IEEE division (x/0 = inf passes, 0/0 = NaN fails).  Passing (query, database index)
+ * pairs are written in ascending query order.  dist_is_float: 0 = int32 distances
+ * (nn_bruteforcel1k2), 1 = float32 (nn_cascading_hash).
+ * Host form: matches int32[yrows,2] capacity, returns status; *count receives the number
+ * of matches. */
+int spv_ratio_test(const uint64_t *idx, const void *dist, int dist_is_float, int yrows,
+                   double min_ratio, int32_t *matches, int32_t *count);
+size_t spv_ratio_test_workspace_bytes(int yrows);
+/* Device form: d_matches int32[yrows,2] capacity, d_count int32[1]. */
+int spv_ratio_test_device(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int yrows,
+                          double min_ratio, int32_t *d_matches, int32_t *d_count, void *d_ws,
+                          size_t ws_bytes, void *stream);
+
 /* Device form of spv_dlt_score_hypotheses: P0 is a HOST pointer (12 doubles), d_P1s
  * double[nhyp,12], d_counts int32[nhyp] (zeroed by the call), d_mask uint8[nhyp,npt] or NULL. */
 int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,

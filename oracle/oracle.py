@@ -186,6 +186,18 @@ def candidates_from_codes(xcodes, ysign, ymask):
     return out
 
 
+def ratio_test_matches(nn_idx, nn_dist, min_ratio):
+    """numpy statement of reference example/ex01_essential_estimation.py:102-106:
+    ratio = d1 / d0.astype('float64'); pass = ratio >= min_ratio; rows (query, nn_idx[:,0])
+    of the passing queries, ascending.  Queries without a neighbour (idx0 == uint64 max, an
+    IndexError in the reference's fancy indexing) never pass."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = nn_dist[:, 1].astype(np.float64) / nn_dist[:, 0].astype(np.float64)
+    ok = (ratio >= min_ratio) & (nn_idx[:, 0] != np.iinfo(np.uint64).max)
+    q = np.flatnonzero(ok)
+    return np.stack([q.astype(np.int32), nn_idx[q, 0].astype(np.int32)], axis=1)
+
+
 def numpy_dlt_null_vector(P0, P1, x, xp):
     """LAPACK SVD null vector of the DLT matrix (reference src/DltTriangulator.h:51-58),
     sign-canonicalised like the oracle (X[3] >= 0)."""

@@ -248,6 +248,33 @@ int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const
   return SPV_OK;
 }
 
+int host_ratio(const uint64_t *idx, const void *dist, int dist_is_float, int yrows, double min_ratio,
+               int32_t *matches, int32_t *count) {
+  if (yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  if (!count) return set_error(SPV_ERR_INVALID, "null pointer");
+  *count = 0;
+  if (yrows == 0) return SPV_OK;
+  if (!idx || !dist || !matches) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  DevBuf di, dd, dm, dc, ws;
+  const size_t wsb = ratio_workspace_bytes(yrows);
+  SPV_TRY(di.alloc((size_t)yrows * 2 * sizeof(uint64_t)));
+  SPV_TRY(dd.alloc((size_t)yrows * 2 * 4));
+  SPV_TRY(dm.alloc((size_t)yrows * 2 * sizeof(int32_t)));
+  SPV_TRY(dc.alloc(sizeof(int32_t)));
+  SPV_TRY(ws.alloc(wsb));
+  hipStream_t st = nullptr;
+  SPV_HIP_CHECK(hipMemcpyAsync(di.p, idx, (size_t)yrows * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dd.p, dist, (size_t)yrows * 2 * 4, hipMemcpyHostToDevice, st));
+  SPV_TRY(ratio_run(di.as<uint64_t>(), dd.p, dist_is_float, yrows, min_ratio, dm.as<int>(), dc.as<int>(),
+                    ws.p, wsb, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(count, dc.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  if (*count > 0)
+    SPV_HIP_CHECK(hipMemcpy(matches, dm.p, (size_t)*count * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SPV_OK;
+}
+
 // Hyperplanes as the reference draws them (src/CascadingHashNn.h:86-100):
 // one std::mt19937 stream, std::normal_distribution<float>(0,1), table-major,
 // then dim (i), then bit (j).
@@ -438,6 +465,19 @@ int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const doubl
                         const double *xp, double *dst) {
   clear_error();
   return host_dlt(P0, P1, npt, x, xp, dst, false);
+}
+int spv_ratio_test(const uint64_t *idx, const void *dist, int dist_is_float, int yrows,
+                   double min_ratio, int32_t *matches, int32_t *count) {
+  clear_error();
+  return host_ratio(idx, dist, dist_is_float, yrows, min_ratio, matches, count);
+}
+size_t spv_ratio_test_workspace_bytes(int yrows) { return yrows < 0 ? 0 : ratio_workspace_bytes(yrows); }
+int spv_ratio_test_device(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int yrows,
+                          double min_ratio, int32_t *d_matches, int32_t *d_count, void *d_ws,
+                          size_t ws_bytes, void *stream) {
+  clear_error();
+  return ratio_run(d_idx, d_dist, dist_is_float, yrows, min_ratio, d_matches, d_count, d_ws, ws_bytes,
+                   static_cast<hipStream_t>(stream));
 }
 int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
                              const double *x, const double *xp, double max_error,

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <algorithm>
+
 #include "../../include/spectavi_amd.h"
 
 namespace spv {
@@ -61,6 +63,12 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
 // ---- DLT (dlt.hip) ------------------------------------------------------------------
 int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x,
             const double *d_xp, double *d_dst, bool want_error, hipStream_t stream);
+
+// ---- ratio test + compaction (match.hip) ---------------------------------------------
+size_t ratio_workspace_bytes(int yrows);
+int ratio_run(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int yrows,
+              double min_ratio, int *d_matches, int *d_count, void *d_ws, size_t ws_bytes,
+              hipStream_t stream);
 
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,

@@ -124,6 +124,51 @@ def dlt_reprojection_error(P0, P1, x, xp):
     return _dlt(clib.spv_dlt_reprojection_error_device, P0, P1, x, xp, 1)
 
 
+clib.spv_ratio_test_workspace_bytes.restype = ct.c_size_t
+clib.spv_ratio_test_workspace_bytes.argtypes = [ct.c_int]
+clib.spv_ratio_test_device.restype = ct.c_int
+clib.spv_ratio_test_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_double, _vp, _vp, _vp, ct.c_size_t, _vp]
+clib.spv_dlt_score_hypotheses_device.restype = ct.c_int
+clib.spv_dlt_score_hypotheses_device.argtypes = [_f64p, _vp, ct.c_int, ct.c_longlong, _vp, _vp, ct.c_double,
+                                                 _vp, _vp, _vp]
+
+
+def ratio_test(idx, dist, min_ratio, workspace=None):
+    """Ratio test + ordered compaction on device.  idx int64 [N,2], dist int32/float32 [N,2]
+    (outputs of l1k2 / cascade).  Returns (matches int32 [N,2] capacity, count int32 [1]);
+    rows [0, count) are (query row, database row).  Asynchronous."""
+    _need(idx, torch.int64, "idx")
+    if dist.dtype == torch.float32:
+        is_float = 1
+    else:
+        _need(dist, torch.int32, "dist")
+        is_float = 0
+    n = idx.shape[0]
+    matches = torch.empty((n, 2), dtype=torch.int32, device=idx.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=idx.device)
+    ws = (workspace or _default_ws).get(clib.spv_ratio_test_workspace_bytes(n), idx.device)
+    check(clib.spv_ratio_test_device(idx.data_ptr(), dist.data_ptr(), is_float, n, float(min_ratio),
+                                     matches.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     _stream()))
+    return matches, count
+
+
+def dlt_score_hypotheses(P0, P1s, x, xp, max_error, want_mask=False):
+    """RANSAC scoring on device: P0 host [3,4]; P1s CUDA float64 [H,3,4]; x,xp CUDA [npt,3].
+    Returns counts int32 [H] (and mask uint8 [H,npt])."""
+    _need(P1s, torch.float64, "P1s")
+    _need(x, torch.float64, "x")
+    _need(xp, torch.float64, "xp")
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    nh, npt = P1s.shape[0], x.shape[0]
+    counts = torch.empty((nh,), dtype=torch.int32, device=x.device)
+    mask = torch.empty((nh, npt), dtype=torch.uint8, device=x.device) if want_mask else None
+    check(clib.spv_dlt_score_hypotheses_device(P0, P1s.data_ptr(), nh, npt, x.data_ptr(), xp.data_ptr(),
+                                               float(max_error), counts.data_ptr(),
+                                               mask.data_ptr() if want_mask else None, _stream()))
+    return (counts, mask) if want_mask else counts
+
+
 def profile_enable(on=True):
     """Bracket the hot kernels with HIP events on their launch stream."""
     clib.spv_profile_enable(1 if on else 0)

@@ -187,3 +187,35 @@ def normalize_to_ubyte_and_multiple_16_dim(x, dtype='float32'):
     xx = np.zeros([xrows, new_dim])
     xx[:, :dim] = x0
     return xx.astype(dtype)
+
+
+# ==================================================================================
+# ratio test + match compaction (reference example/ex01_essential_estimation.py:102-106)
+# ==================================================================================
+_spv_ratio_test = clib.spv_ratio_test
+_spv_ratio_test.restype = ct.c_int
+_spv_ratio_test.argtypes = [ndpointer(ct.c_uint64, flags="C_CONTIGUOUS"), ct.c_void_p, ct.c_int, ct.c_int,
+                            ct.c_double, ndpointer(ct.c_int32, flags="C_CONTIGUOUS"),
+                            ct.POINTER(ct.c_int32)]
+
+
+def ratio_test_matches(nn_idx, nn_dist, min_ratio):
+    """
+    The match filter of the reference's pipeline, on the GPU:
+    ``pass = nn_dist[:,1] / nn_dist[:,0].astype('float64') >= min_ratio`` and the
+    compaction ``(where(pass), nn_idx[pass, 0])``.  Returns int32 [nmatch, 2] rows
+    (query row, database row) in ascending query order.  Queries without any
+    neighbour never pass.
+    """
+    nn_idx = np.ascontiguousarray(nn_idx, dtype=np.uint64)
+    if nn_dist.dtype == np.float32:
+        is_float, nn_dist = 1, np.ascontiguousarray(nn_dist)
+    else:
+        is_float, nn_dist = 0, np.ascontiguousarray(nn_dist, dtype=np.int32)
+    yrows = nn_idx.shape[0]
+    assert nn_idx.shape == (yrows, 2) and nn_dist.shape == (yrows, 2)
+    matches = np.empty((yrows, 2), np.int32)
+    count = ct.c_int32(0)
+    check(_spv_ratio_test(nn_idx, nn_dist.ctypes.data, is_float, yrows, float(min_ratio), matches,
+                          ct.byref(count)))
+    return matches[:count.value].copy()
