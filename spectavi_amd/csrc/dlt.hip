@@ -53,7 +53,7 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
 #pragma unroll
     for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
 
-  const double eps = 1e-15;
+  const double eps2 = 1e-30;  // (1e-15)^2
   for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
     bool rotated = false;
 #pragma unroll
@@ -67,12 +67,15 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
           beta += A[i][q] * A[i][q];
           gamma += A[i][p] * A[i][q];
         }
-        const double lim = eps * sqrt(alpha * beta);
-        if (fabs(gamma) > lim && gamma != 0.0) {
+        // skip test |gamma| > eps*sqrt(alpha*beta), squared to avoid the square root
+        if (gamma * gamma > eps2 * (alpha * beta)) {
           rotated = true;
-          const double zeta = (beta - alpha) / (2.0 * gamma);
-          const double tt = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double tn = zeta < 0.0 ? -tt : tt;
+          // tan of the rotation angle, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with
+          // zeta = (beta - alpha) / (2 gamma), rearranged to one sqrt and one division
+          const double dd = beta - alpha;
+          const double g2 = 2.0 * gamma;
+          const double hh = sqrt(dd * dd + g2 * g2);
+          const double tn = g2 / (dd + (dd < 0.0 ? -hh : hh));
           const double cs = 1.0 / sqrt(1.0 + tn * tn);
           const double sn = cs * tn;
 #pragma unroll

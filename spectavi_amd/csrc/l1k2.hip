@@ -469,7 +469,7 @@ L1K2Plan l1k2_plan(int xrows, int yrows, int dim) {
   p.qblocks = std::max(1, (yrows + qlanes * q - 1) / (qlanes * q));
   // database slices: enough workgroups to fill 256 CUs x 2 several times over,
   // each slice a multiple of the tile and <= 65536 rows (16-bit local index)
-  static const int want_blocks = std::max(1, env_int("SPECTAVI_L1K2_BLOCKS", 4096));
+  static const int want_blocks = std::max(1, env_int("SPECTAVI_L1K2_BLOCKS", 16384));
   int s_target = std::max(1, (want_blocks + p.qblocks - 1) / p.qblocks);
   long long rows = (xrows + s_target - 1) / s_target;
   rows = (rows + kTileRows - 1) / kTileRows * kTileRows;
