@@ -45,6 +45,12 @@ int spv_device_count(void);
 /* Device used by the host-pointer entry points of this process (default:
  * environment SPECTAVI_DEVICE, else 0). */
 int spv_set_device(int device);
+/* Shard the host-pointer entry points over several devices of this node (default:
+ * environment SPECTAVI_DEVICES = "0,1,..." or "all", else the single device above).
+ * Queries / points are split into contiguous balanced shards, the database is
+ * replicated, and each shard is written straight into its slice of the caller's
+ * output by a host thread per device; a device may be listed more than once. */
+int spv_set_devices(const int *devices, int count);
 /* Library version string. */
 const char *spv_version(void);
 

@@ -58,6 +58,15 @@ def set_device(device):
     check(clib.spv_set_device(int(device)))
 
 
+def set_devices(devices):
+    """Shard the host-array entry points (feature.*, mvg.*) over these GPUs of the node."""
+    devices = [int(d) for d in devices]
+    arr = (ct.c_int * len(devices))(*devices)
+    clib.spv_set_devices.restype = ct.c_int
+    clib.spv_set_devices.argtypes = [ct.POINTER(ct.c_int), ct.c_int]
+    check(clib.spv_set_devices(arr, len(devices)))
+
+
 def set_hash_seed(seed=None):
     """Fix the hyperplane seed of nn_cascading_hash (None: back to std::random_device)."""
     if seed is None:

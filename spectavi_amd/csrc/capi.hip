@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <random>
 #include <vector>
@@ -27,6 +28,7 @@ thread_local char g_message[512] = "";
 
 std::mutex g_cfg_mutex;
 int g_device = -1;  // -1: not chosen yet
+std::vector<int> g_devices;  // empty: not chosen yet
 bool g_seed_fixed = false;
 uint32_t g_seed = 0;
 }  // namespace
@@ -73,23 +75,78 @@ ProfScope::~ProfScope() {
   g_prof[name_].emplace_back(start_, stop);
 }
 
-int ensure_device() {
-  int dev;
-  {
-    std::lock_guard<std::mutex> lk(g_cfg_mutex);
-    if (g_device < 0) {
-      const char *e = getenv("SPECTAVI_DEVICE");
-      g_device = (e && *e) ? atoi(e) : 0;
-    }
-    dev = g_device;
-  }
+static int use_device(int dev) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0)
     return set_error(SPV_ERR_HIP, "no HIP device available (%s); libspectavi has no CPU fallback",
                      e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-  if (dev >= count) return set_error(SPV_ERR_HIP, "SPECTAVI_DEVICE=%d but only %d devices", dev, count);
+  if (dev < 0 || dev >= count)
+    return set_error(SPV_ERR_HIP, "device %d requested but only %d devices are visible", dev, count);
   SPV_HIP_CHECK(hipSetDevice(dev));
+  return SPV_OK;
+}
+
+// Devices the host-pointer entry points shard over.  One entry unless
+// spv_set_devices() / SPECTAVI_DEVICES ("0,1,2,3" or "all") asked for more.
+static std::vector<int> device_list() {
+  std::lock_guard<std::mutex> lk(g_cfg_mutex);
+  if (g_devices.empty()) {
+    const char *e = getenv("SPECTAVI_DEVICES");
+    if (e && *e) {
+      if (!strcmp(e, "all")) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) == hipSuccess)
+          for (int d = 0; d < count; ++d) g_devices.push_back(d);
+      } else {
+        for (const char *c = e; *c;) {
+          char *end = nullptr;
+          const long v = strtol(c, &end, 10);
+          if (end == c) break;
+          g_devices.push_back((int)v);
+          c = (*end == ',') ? end + 1 : end;
+        }
+      }
+    }
+    if (g_devices.empty()) {
+      if (g_device < 0) {
+        const char *d = getenv("SPECTAVI_DEVICE");
+        g_device = (d && *d) ? atoi(d) : 0;
+      }
+      g_devices.push_back(g_device);
+    }
+  }
+  return g_devices;
+}
+
+int ensure_device() { return use_device(device_list()[0]); }
+
+// Splits [0, total) into contiguous balanced shards, one per configured device, and runs
+// fn(device, lo, hi) on a host thread per shard (every row of the hot path is independent:
+// the reference parallelises the same loop with OpenMP, src/BruteForceNnL1K2.h:92).  Each
+// shard writes straight into its slice of the caller's output, so no gather is needed
+// inside one process.
+template <typename Fn>
+static int run_sharded(long long total, Fn fn) {
+  const std::vector<int> devs = device_list();
+  const int G = (int)std::min<long long>((long long)devs.size(), std::max<long long>(total, 1));
+  if (G <= 1) return fn(devs[0], 0LL, total);
+  std::vector<int> status(G, SPV_OK);
+  std::vector<std::string> message(G);
+  std::vector<std::thread> threads;
+  const long long base = total / G, extra = total % G;
+  for (int r = 0; r < G; ++r) {
+    const long long lo = r * base + std::min<long long>(r, extra);
+    const long long hi = lo + base + (r < extra ? 1 : 0);
+    threads.emplace_back([&, r, lo, hi] {
+      status[r] = fn(devs[r], lo, hi);
+      if (status[r] != SPV_OK) message[r] = g_message;
+    });
+  }
+  for (auto &t : threads) t.join();
+  for (int r = 0; r < G; ++r)
+    if (status[r] != SPV_OK)
+      return set_error(status[r], "device %d: %s", devs[r], message[r].c_str());
   return SPV_OK;
 }
 
@@ -122,15 +179,15 @@ struct DevBuf {
     if (_s != SPV_OK) return _s; \
   } while (0)
 
-int host_l1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim, uint64_t *idx,
-              int32_t *dist) {
+int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
+                  uint64_t *idx, int32_t *dist) {
   if (xrows < 0 || yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
   if (dim <= 0 || dim % 16 != 0)
     return set_error(SPV_ERR_INVALID,
                      "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
   if (yrows == 0) return SPV_OK;
   if (!y || !idx || !dist || (xrows > 0 && !x)) return set_error(SPV_ERR_INVALID, "null pointer");
-  SPV_TRY(ensure_device());
+  SPV_TRY(use_device(dev));
   const size_t xb = (size_t)xrows * dim, yb = (size_t)yrows * dim;
   const size_t wsb = spv_l1k2_workspace_bytes(xrows, yrows, dim);
   DevBuf dx, dy, di, dd, ws;
@@ -152,6 +209,15 @@ int host_l1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
   return SPV_OK;
 }
 
+int host_l1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim, uint64_t *idx,
+              int32_t *dist) {
+  if (yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  return run_sharded(yrows, [&](int dev, long long lo, long long hi) {
+    return host_l1k2_one(dev, x, y ? y + (size_t)lo * dim : y, xrows, (int)(hi - lo), dim,
+                         idx ? idx + 2 * lo : idx, dist ? dist + 2 * lo : dist);
+  });
+}
+
 int check_cascade_args(int xrows, int yrows, int dim, int m, int n, int g) {
   if (xrows < 0 || yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
   if (dim <= 0 || dim % 16 != 0)
@@ -164,13 +230,13 @@ int check_cascade_args(int xrows, int yrows, int dim, int m, int n, int g) {
   return SPV_OK;
 }
 
-int host_cascade(const float *x, const float *y, int xrows, int yrows, int dim, int m, int n,
-                 int g, const float *dict, uint64_t *idx, float *dist, int32_t *ncand) {
+int host_cascade_one(int dev, const float *x, const float *y, int xrows, int yrows, int dim, int m,
+                     int n, int g, const float *dict, uint64_t *idx, float *dist, int32_t *ncand) {
   SPV_TRY(check_cascade_args(xrows, yrows, dim, m, n, g));
   if (yrows == 0) return SPV_OK;
   if (!y || !idx || !dist || !dict || (xrows > 0 && !x))
     return set_error(SPV_ERR_INVALID, "null pointer");
-  SPV_TRY(ensure_device());
+  SPV_TRY(use_device(dev));
   const size_t xb = (size_t)xrows * dim * sizeof(float), yb = (size_t)yrows * dim * sizeof(float);
   const size_t db = (size_t)n * dim * m * sizeof(float);
   const size_t wsb = cascade_workspace_bytes(xrows, yrows, dim, m, n, g);
@@ -199,12 +265,22 @@ int host_cascade(const float *x, const float *y, int xrows, int yrows, int dim, 
   return SPV_OK;
 }
 
-int host_dlt(const double *P0, const double *P1, int npt, const double *x, const double *xp,
-             double *dst, bool want_error) {
+int host_cascade(const float *x, const float *y, int xrows, int yrows, int dim, int m, int n,
+                 int g, const float *dict, uint64_t *idx, float *dist, int32_t *ncand) {
+  SPV_TRY(check_cascade_args(xrows, yrows, dim, m, n, g));
+  return run_sharded(yrows, [&](int dev, long long lo, long long hi) {
+    return host_cascade_one(dev, x, y ? y + (size_t)lo * dim : y, xrows, (int)(hi - lo), dim, m, n, g,
+                            dict, idx ? idx + 2 * lo : idx, dist ? dist + 2 * lo : dist,
+                            ncand ? ncand + lo : ncand);
+  });
+}
+
+int host_dlt_one(int dev, const double *P0, const double *P1, int npt, const double *x,
+                 const double *xp, double *dst, bool want_error) {
   if (npt < 0) return set_error(SPV_ERR_INVALID, "negative point count");
   if (npt == 0) return SPV_OK;
   if (!P0 || !P1 || !x || !xp || !dst) return set_error(SPV_ERR_INVALID, "null pointer");
-  SPV_TRY(ensure_device());
+  SPV_TRY(use_device(dev));
   const size_t ib = (size_t)npt * 3 * sizeof(double);
   const size_t ob = (size_t)npt * (want_error ? 1 : 4) * sizeof(double);
   DevBuf dx, dxp, dd;
@@ -218,6 +294,16 @@ int host_dlt(const double *P0, const double *P1, int npt, const double *x, const
   SPV_HIP_CHECK(hipMemcpyAsync(dst, dd.p, ob, hipMemcpyDeviceToHost, st));
   SPV_HIP_CHECK(hipStreamSynchronize(st));
   return SPV_OK;
+}
+
+int host_dlt(const double *P0, const double *P1, int npt, const double *x, const double *xp,
+             double *dst, bool want_error) {
+  if (npt < 0) return set_error(SPV_ERR_INVALID, "negative point count");
+  const int cols = want_error ? 1 : 4;
+  return run_sharded(npt, [&](int dev, long long lo, long long hi) {
+    return host_dlt_one(dev, P0, P1, (int)(hi - lo), x ? x + 3 * lo : x, xp ? xp + 3 * lo : xp,
+                        dst ? dst + cols * lo : dst, want_error);
+  });
 }
 
 int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const double *x,
@@ -343,6 +429,17 @@ int spv_set_device(int device) {
   if (device < 0) return set_error(SPV_ERR_INVALID, "device %d", device);
   std::lock_guard<std::mutex> lk(g_cfg_mutex);
   g_device = device;
+  g_devices.assign(1, device);
+  return SPV_OK;
+}
+int spv_set_devices(const int *devices, int count) {
+  clear_error();
+  if (count < 1 || !devices) return set_error(SPV_ERR_INVALID, "need at least one device");
+  for (int i = 0; i < count; ++i)
+    if (devices[i] < 0) return set_error(SPV_ERR_INVALID, "device %d", devices[i]);
+  std::lock_guard<std::mutex> lk(g_cfg_mutex);
+  g_devices.assign(devices, devices + count);
+  g_device = devices[0];
   return SPV_OK;
 }
 

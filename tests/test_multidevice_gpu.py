@@ -1,0 +1,51 @@
+"""GPU: in-process sharding of the host-array entry points over a device list.  The box has
+one GPU, so the list names device 0 three times (allowed): this exercises the shard bounds,
+the per-shard threads and the direct writes into output slices; results must not change."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def three_shards():
+    import spectavi_amd
+    spectavi_amd.set_devices([0, 0, 0])
+    yield
+    spectavi_amd.set_devices([0])
+
+
+def test_l1k2_cascade_dlt_sharded(oracle, three_shards):
+    from spectavi_amd import feature, mvg
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 256, (3000, 128), dtype=np.uint8)
+    y = rng.integers(0, 256, (1001, 128), dtype=np.uint8)  # ragged over 3 shards
+    idx, dist = feature.nn_bruteforcel1k2(x, y)
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    idx, dist = feature.nn_bruteforcel1k2(x, y[:2])         # fewer rows than devices
+    assert np.array_equal(idx, oidx[:2]) and np.array_equal(dist, odist[:2])
+
+    xf, yf = x.astype(np.float32) - 128, y.astype(np.float32) - 128
+    d = rng.standard_normal((2, 128, 8)).astype(np.float32)
+    cidx, cdist, ncand = feature.nn_cascading_hash_with_dict(xf, yf, d, g=2, return_ncand=True)
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(xf, yf, 8, 2, 2, d)
+    assert np.array_equal(cidx, oidx) and np.array_equal(cdist, odist) and np.array_equal(ncand, oncand)
+
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((10007, 4))
+    X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert np.max(np.abs(X - oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
+    e = mvg.dlt_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert e.shape == (10007, 1) and float(e.max()) < 1e-6
+
+
+def test_bad_device_is_reported():
+    import spectavi_amd
+    from spectavi_amd import feature
+    spectavi_amd.set_devices([0, 99])
+    try:
+        with pytest.raises(spectavi_amd.SpectaviError):
+            feature.nn_bruteforcel1k2(np.zeros((8, 16), np.uint8), np.zeros((8, 16), np.uint8))
+    finally:
+        spectavi_amd.set_devices([0])
