@@ -15,8 +15,8 @@
 //
 // The SVD itself lives in Eigen (JacobiSVD, version unpinned by the reference
 // build, absent here).  It is restated as a one-sided (Hestenes) Jacobi
-// iteration in fp64 -- the same operation sequence the HIP kernel executes, with
-// floating-point contraction disabled on both sides -- and pinned two ways in
+// iteration in fp64 -- the same operation sequence the HIP kernel executes, fused
+// multiply-adds written explicitly and implicit contraction disabled on both sides -- and pinned two ways in
 // tests/test_oracle.py: (a) the reference's own test properties
 // (test/test_mvg.py:94-125: reprojection error < 1e-3 and X == X0 up to scale on
 // noise-free random cameras), (b) numpy.linalg.svd (LAPACK) null vectors of the
@@ -41,10 +41,10 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
   const double up = xp[0] / xp[2], vp = xp[1] / xp[2];
   double A[4][4], V[4][4];
   for (int c = 0; c < 4; ++c) {
-    A[0][c] = u * P0[8 + c] - P0[0 + c];
-    A[1][c] = v * P0[8 + c] - P0[4 + c];
-    A[2][c] = up * P1[8 + c] - P1[0 + c];
-    A[3][c] = vp * P1[8 + c] - P1[4 + c];
+    A[0][c] = std::fma(u, P0[8 + c], -P0[0 + c]);
+    A[1][c] = std::fma(v, P0[8 + c], -P0[4 + c]);
+    A[2][c] = std::fma(up, P1[8 + c], -P1[0 + c]);
+    A[3][c] = std::fma(vp, P1[8 + c], -P1[4 + c]);
   }
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
@@ -56,9 +56,9 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
       for (int q = p + 1; q < 4; ++q) {
         double alpha = 0.0, beta = 0.0, gamma = 0.0;
         for (int i = 0; i < 4; ++i) {
-          alpha += A[i][p] * A[i][p];
-          beta += A[i][q] * A[i][q];
-          gamma += A[i][p] * A[i][q];
+          alpha = std::fma(A[i][p], A[i][p], alpha);
+          beta = std::fma(A[i][q], A[i][q], beta);
+          gamma = std::fma(A[i][p], A[i][q], gamma);
         }
         // skip test |gamma| > eps*sqrt(alpha*beta), squared to avoid the square root
         if (gamma * gamma > eps2 * (alpha * beta)) {
@@ -67,17 +67,17 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
           // zeta = (beta - alpha) / (2 gamma), rearranged to one sqrt and one division
           const double dd = beta - alpha;
           const double g2 = 2.0 * gamma;
-          const double hh = std::sqrt(dd * dd + g2 * g2);
+          const double hh = std::sqrt(std::fma(dd, dd, g2 * g2));
           const double tn = g2 / (dd + (dd < 0.0 ? -hh : hh));
-          const double cs = 1.0 / std::sqrt(1.0 + tn * tn);
+          const double cs = 1.0 / std::sqrt(std::fma(tn, tn, 1.0));
           const double sn = cs * tn;
           for (int i = 0; i < 4; ++i) {
             const double ap = A[i][p], aq = A[i][q];
-            A[i][p] = cs * ap - sn * aq;
-            A[i][q] = sn * ap + cs * aq;
+            A[i][p] = std::fma(cs, ap, -(sn * aq));
+            A[i][q] = std::fma(sn, ap, cs * aq);
             const double vp_ = V[i][p], vq_ = V[i][q];
-            V[i][p] = cs * vp_ - sn * vq_;
-            V[i][q] = sn * vp_ + cs * vq_;
+            V[i][p] = std::fma(cs, vp_, -(sn * vq_));
+            V[i][q] = std::fma(sn, vp_, cs * vq_);
           }
         }
       }
@@ -88,7 +88,7 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
   int kbest = 0;
   for (int c = 0; c < 4; ++c) {
     double nn = 0.0;
-    for (int i = 0; i < 4; ++i) nn += A[i][c] * A[i][c];
+    for (int i = 0; i < 4; ++i) nn = std::fma(A[i][c], A[i][c], nn);
     if (c == 0 || nn < best) {
       best = nn;
       kbest = c;
@@ -97,7 +97,7 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
   double xv[4];
   for (int i = 0; i < 4; ++i) xv[i] = V[i][kbest];
   double nrm = 0.0;
-  for (int i = 0; i < 4; ++i) nrm += xv[i] * xv[i];
+  for (int i = 0; i < 4; ++i) nrm = std::fma(xv[i], xv[i], nrm);
   nrm = std::sqrt(nrm);
   bool neg;
   if (xv[3] != 0.0)
@@ -119,7 +119,7 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
 inline void reproject(const double *P, const double *X, double *r) {
   for (int k = 0; k < 3; ++k) {
     double a = 0.0;
-    for (int c = 0; c < 4; ++c) a += P[4 * k + c] * X[c];
+    for (int c = 0; c < 4; ++c) a = std::fma(P[4 * k + c], X[c], a);
     r[k] = a;
   }
 }
@@ -155,7 +155,7 @@ void oracle_dlt_reprojection_error(const double *P0, const double *P1, int npt, 
     reproject(P1, s.X, r1);
     const double e0x = r0[0] / r0[2] - s.u, e0y = r0[1] / r0[2] - s.v;
     const double e1x = r1[0] / r1[2] - s.up, e1y = r1[1] / r1[2] - s.vp;
-    dst[i] = std::sqrt(e0x * e0x + e0y * e0y) + std::sqrt(e1x * e1x + e1y * e1y);
+    dst[i] = std::sqrt(std::fma(e0x, e0x, e0y * e0y)) + std::sqrt(std::fma(e1x, e1x, e1y * e1y));
   }
 }
 
@@ -198,7 +198,7 @@ void oracle_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, 
       reproject(P1, s.X, r1);
       const double e0x = r0[0] / r0[2] - s.u, e0y = r0[1] / r0[2] - s.v;
       const double e1x = r1[0] / r1[2] - s.up, e1y = r1[1] / r1[2] - s.vp;
-      const double err = std::sqrt(e0x * e0x + e0y * e0y) + std::sqrt(e1x * e1x + e1y * e1y);
+      const double err = std::sqrt(std::fma(e0x, e0x, e0y * e0y)) + std::sqrt(std::fma(e1x, e1x, e1y * e1y));
       const double dc0 = s0 / n0 * r0[2] / s.X[3];
       const double dc1 = s1 / n1 * r1[2] / s.X[3];
       const bool in = (err <= max_error) && (dc0 > 0) && (dc1 > 0);

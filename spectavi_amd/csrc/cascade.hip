@@ -61,13 +61,17 @@ __global__ void repack_dict_kernel(const float *__restrict__ dict, float *__rest
 }
 
 // ---------------------------------------------------------------------------------
-// 2/3. projections, codes, uint8 image.  One lane per row; the row is read 16
-// floats at a time (lane-private, 64-byte pieces), the MC accumulators of one
-// table live in registers, dictionary values arrive as wave-uniform scalars.
+// 2/3. projections, codes, uint8 image.  Each lane owns two rows; the MC accumulators
+// of one table per row live in registers; the table's hyperplanes are staged in LDS
+// (128 dims at a time) and read by broadcast ds_read_b128 -- one LDS dword feeds
+// 64 lanes x 2 rows.  The projection of (row, bit) is ONE dim-ordered fp32 FMA chain.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2u8(float v) {
   return (uint32_t)((int)v + 128) & 0xFFu;  // trunc toward zero, wrap mod 256
 }
+
+constexpr int kProjRows = 2;     // rows per lane (register blocking against the LDS broadcast)
+constexpr int kProjChunk = 128;  // hyperplane dims staged in LDS at a time
 
 template <int MC, bool IS_QUERY, int GMAX>
 __global__ __launch_bounds__(kThreads) void project_kernel(
@@ -76,78 +80,108 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
     uint32_t *__restrict__ codes,        // [n][nrows] sign codes
     uint32_t *__restrict__ masks,        // [n][nrows] (queries only)
     uint8_t *__restrict__ u8img) {       // [nrows][dim]
-  const int r = blockIdx.x * kThreads + threadIdx.x;
-  const int rr = min(r, nrows - 1);
-  const float4 *src = reinterpret_cast<const float4 *>(rows + (size_t)rr * dim);
+  constexpr int R = kProjRows;
+  __shared__ float4 sd[kProjChunk * MC / 4];  // hyperplanes [dims of the chunk][MC]
+  // accumulator start values: +0 for real hyperplanes, +inf for the zero-padded ones so
+  // that they are never picked as "least confident" (their code bits are masked off)
+  __shared__ float sinit[MC];
+  const int t = threadIdx.x;
+  if (t < MC) sinit[t] = t < m ? 0.f : __builtin_inff();
+  __syncthreads();
+  int r[R];
+  const float4 *src[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    r[k] = (blockIdx.x * R + k) * kThreads + t;
+    src[k] = reinterpret_cast<const float4 *>(rows + (size_t)min(r[k], nrows - 1) * dim);
+  }
   for (int j = 0; j < n; ++j) {
-    float acc[MC];
+    float acc[R][MC];
 #pragma unroll
-    for (int b = 0; b < MC; ++b) acc[b] = 0.f;
-    const float *dj = dictp + (size_t)j * dim * MC;
-    for (int i0 = 0; i0 < dim; i0 += 16) {
-      float xv[16];
+    for (int b = 0; b < MC; ++b) {
+      const float a0 = sinit[b];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 v = src[i0 / 4 + c];
-        xv[4 * c + 0] = v.x;
-        xv[4 * c + 1] = v.y;
-        xv[4 * c + 2] = v.z;
-        xv[4 * c + 3] = v.w;
-      }
-      if (j == 0 && r < nrows) {
-        uint4 pk;
-        pk.x = f2u8(xv[0]) | (f2u8(xv[1]) << 8) | (f2u8(xv[2]) << 16) | (f2u8(xv[3]) << 24);
-        pk.y = f2u8(xv[4]) | (f2u8(xv[5]) << 8) | (f2u8(xv[6]) << 16) | (f2u8(xv[7]) << 24);
-        pk.z = f2u8(xv[8]) | (f2u8(xv[9]) << 8) | (f2u8(xv[10]) << 16) | (f2u8(xv[11]) << 24);
-        pk.w = f2u8(xv[12]) | (f2u8(xv[13]) << 8) | (f2u8(xv[14]) << 16) | (f2u8(xv[15]) << 24);
-        *reinterpret_cast<uint4 *>(u8img + (size_t)r * dim + i0) = pk;
-      }
-#pragma unroll
-      for (int ii = 0; ii < 16; ++ii) {
-        const float *dr = dj + (size_t)(i0 + ii) * MC;  // wave-uniform -> scalar loads
-#pragma unroll
-        for (int b = 0; b < MC; ++b) acc[b] = __builtin_fmaf(xv[ii], dr[b], acc[b]);
-      }
+      for (int k = 0; k < R; ++k) acc[k][b] = a0;
     }
-    uint32_t code = 0;
+    for (int c0 = 0; c0 < dim; c0 += kProjChunk) {
+      const int cw = min(kProjChunk, dim - c0);  // multiple of 16
+      __syncthreads();
+      const float4 *dsrc = reinterpret_cast<const float4 *>(dictp + ((size_t)j * dim + c0) * MC);
+      for (int e = t; e < cw * MC / 4; e += kThreads) sd[e] = dsrc[e];
+      __syncthreads();
+      for (int i0 = 0; i0 < cw; i0 += 4) {
+        float4 xv[R];
 #pragma unroll
-    for (int b = 0; b < MC; ++b)
-      if (b < m && acc[b] >= 0.f) code |= 1u << b;
-    if (r < nrows) codes[(size_t)j * nrows + r] = code;
-    if (IS_QUERY) {
-      // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
-      // order so a strict < keeps the lower bit on equal magnitude
-      float best[GMAX];
-      int bbit[GMAX];
+        for (int k = 0; k < R; ++k) xv[k] = src[k][(c0 + i0) / 4];
+        if (j == 0) {
 #pragma unroll
-      for (int t = 0; t < GMAX; ++t) {
-        best[t] = __builtin_inff();
-        bbit[t] = -1;
-      }
-#pragma unroll
-      for (int b = 0; b < MC; ++b) {
-        if (b < m) {
-          float v = fabsf(acc[b]);
-          int vb = b;
-#pragma unroll
-          for (int t = 0; t < GMAX; ++t) {
-            if (t < g) {
-              const bool lt = v < best[t];
-              const float tv = best[t];
-              const int tb = bbit[t];
-              best[t] = lt ? v : tv;
-              bbit[t] = lt ? vb : tb;
-              v = lt ? tv : v;
-              vb = lt ? tb : vb;
+          for (int k = 0; k < R; ++k) {
+            if (r[k] < nrows) {
+              const uint32_t pk = f2u8(xv[k].x) | (f2u8(xv[k].y) << 8) | (f2u8(xv[k].z) << 16) |
+                                  (f2u8(xv[k].w) << 24);
+              *reinterpret_cast<uint32_t *>(u8img + (size_t)r[k] * dim + c0 + i0) = pk;
             }
           }
         }
-      }
-      uint32_t mask = 0;
 #pragma unroll
-      for (int t = 0; t < GMAX; ++t)
-        if (t < g && bbit[t] >= 0) mask |= 1u << bbit[t];
-      if (r < nrows) masks[(size_t)j * nrows + r] = mask;
+        for (int ii = 0; ii < 4; ++ii) {
+          // all lanes read the same hyperplane row: LDS broadcast, MC/4 x ds_read_b128
+          float dv[MC];
+#pragma unroll
+          for (int b4 = 0; b4 < MC / 4; ++b4) {
+            const float4 d4 = sd[(i0 + ii) * (MC / 4) + b4];
+            dv[4 * b4 + 0] = d4.x;
+            dv[4 * b4 + 1] = d4.y;
+            dv[4 * b4 + 2] = d4.z;
+            dv[4 * b4 + 3] = d4.w;
+          }
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const float xs = ii == 0 ? xv[k].x : (ii == 1 ? xv[k].y : (ii == 2 ? xv[k].z : xv[k].w));
+#pragma unroll
+            for (int b = 0; b < MC; ++b) acc[k][b] = __builtin_fmaf(xs, dv[b], acc[k][b]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      uint32_t code = 0;
+#pragma unroll
+      for (int b = 0; b < MC; ++b) code |= (acc[k][b] >= 0.f ? 1u : 0u) << b;
+      code &= 0xFFFFFFFFu >> (32 - m);  // padded hyperplanes project to +0: drop their bits
+      if (r[k] < nrows) codes[(size_t)j * nrows + r[k]] = code;
+      if (IS_QUERY) {
+        // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
+        // order so a strict < keeps the lower bit on equal magnitude
+        float best[GMAX];
+        int bbit[GMAX];
+#pragma unroll
+        for (int q = 0; q < GMAX; ++q) {
+          best[q] = __builtin_inff();
+          bbit[q] = -1;
+        }
+#pragma unroll
+        for (int b = 0; b < MC; ++b) {
+          float v = fabsf(acc[k][b]);  // +inf for padded hyperplanes: never inserted
+          int vb = b;
+#pragma unroll
+          for (int q = 0; q < GMAX; ++q) {
+            const bool lt = q < g && v < best[q];
+            const float tv = best[q];
+            const int tb = bbit[q];
+            best[q] = lt ? v : tv;
+            bbit[q] = lt ? vb : tb;
+            v = lt ? tv : v;
+            vb = lt ? tb : vb;
+          }
+        }
+        uint32_t mask = 0;
+#pragma unroll
+        for (int q = 0; q < GMAX; ++q)
+          if (q < g && bbit[q] >= 0) mask |= 1u << bbit[q];
+        if (r[k] < nrows) masks[(size_t)j * nrows + r[k]] = mask;
+      }
     }
   }
 }
@@ -460,7 +494,8 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
                     const float *dictp, uint32_t *codes, uint32_t *masks, uint8_t *img,
                     hipStream_t stream) {
   if (nrows <= 0) return;
-  const dim3 grid((nrows + kThreads - 1) / kThreads), block(kThreads);
+  const int rows_per_block = kThreads * kProjRows;
+  const dim3 grid((nrows + rows_per_block - 1) / rows_per_block), block(kThreads);
   constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
 #define SPV_LAUNCH_PROJECT(MCV)                                                                 \
   if (g <= G1)                                                                                  \

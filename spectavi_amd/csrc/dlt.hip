@@ -11,9 +11,9 @@
 //   V accumulates them; the column of smallest norm is the right singular
 //   vector of the smallest singular value = V.col(3) of the reference (:56-58).
 //
-// The arithmetic is written without fused multiply-add (this file is compiled
-// with -ffp-contract=off) so that the CPU oracle, which executes the same
-// operation sequence, reproduces it bit for bit.
+// Every fused multiply-add is written explicitly and implicit contraction is off
+// (-ffp-contract=off), so the CPU oracle, which executes the same operation
+// sequence with std::fma, reproduces the result bit for bit.
 //
 // Sign: Eigen's sign of V.col(3) is arbitrary; the result is canonicalised to
 // X[3] >= 0 (first nonzero component positive when X[3] == 0).
@@ -42,10 +42,10 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
   double A[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    A[0][c] = u * cam.p0[8 + c] - cam.p0[0 + c];
-    A[1][c] = v * cam.p0[8 + c] - cam.p0[4 + c];
-    A[2][c] = up * cam.p1[8 + c] - cam.p1[0 + c];
-    A[3][c] = vp * cam.p1[8 + c] - cam.p1[4 + c];
+    A[0][c] = __builtin_fma(u, cam.p0[8 + c], -cam.p0[0 + c]);
+    A[1][c] = __builtin_fma(v, cam.p0[8 + c], -cam.p0[4 + c]);
+    A[2][c] = __builtin_fma(up, cam.p1[8 + c], -cam.p1[0 + c]);
+    A[3][c] = __builtin_fma(vp, cam.p1[8 + c], -cam.p1[4 + c]);
   }
   double V[4][4];
 #pragma unroll
@@ -63,9 +63,9 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
         double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          alpha += A[i][p] * A[i][p];
-          beta += A[i][q] * A[i][q];
-          gamma += A[i][p] * A[i][q];
+          alpha = __builtin_fma(A[i][p], A[i][p], alpha);
+          beta = __builtin_fma(A[i][q], A[i][q], beta);
+          gamma = __builtin_fma(A[i][p], A[i][q], gamma);
         }
         // skip test |gamma| > eps*sqrt(alpha*beta), squared to avoid the square root
         if (gamma * gamma > eps2 * (alpha * beta)) {
@@ -74,18 +74,18 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
           // zeta = (beta - alpha) / (2 gamma), rearranged to one sqrt and one division
           const double dd = beta - alpha;
           const double g2 = 2.0 * gamma;
-          const double hh = sqrt(dd * dd + g2 * g2);
+          const double hh = sqrt(__builtin_fma(dd, dd, g2 * g2));
           const double tn = g2 / (dd + (dd < 0.0 ? -hh : hh));
-          const double cs = 1.0 / sqrt(1.0 + tn * tn);
+          const double cs = 1.0 / sqrt(__builtin_fma(tn, tn, 1.0));
           const double sn = cs * tn;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const double ap = A[i][p], aq = A[i][q];
-            A[i][p] = cs * ap - sn * aq;
-            A[i][q] = sn * ap + cs * aq;
+            A[i][p] = __builtin_fma(cs, ap, -(sn * aq));
+            A[i][q] = __builtin_fma(sn, ap, cs * aq);
             const double vp_ = V[i][p], vq_ = V[i][q];
-            V[i][p] = cs * vp_ - sn * vq_;
-            V[i][q] = sn * vp_ + cs * vq_;
+            V[i][p] = __builtin_fma(cs, vp_, -(sn * vq_));
+            V[i][q] = __builtin_fma(sn, vp_, cs * vq_);
           }
         }
       }
@@ -99,7 +99,7 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
   for (int c = 0; c < 4; ++c) {
     double nn = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nn += A[i][c] * A[i][c];
+    for (int i = 0; i < 4; ++i) nn = __builtin_fma(A[i][c], A[i][c], nn);
     if (c == 0 || nn < best) {
       best = nn;
       kbest = c;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
   // renormalise (V is orthogonal up to rounding) and canonicalise the sign
   double nrm = 0.0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) nrm += xv[i] * xv[i];
+  for (int i = 0; i < 4; ++i) nrm = __builtin_fma(xv[i], xv[i], nrm);
   nrm = sqrt(nrm);
   bool neg = false;
   if (xv[3] != 0.0)
@@ -159,15 +159,15 @@ __global__ __launch_bounds__(kDltThreads) void dlt_kernel(Cameras cam, long long
       double a = 0.0, b = 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        a += cam.p0[4 * r + c] * X[c];
-        b += cam.p1[4 * r + c] * X[c];
+        a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
+        b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
       }
       r0[r] = a;
       r1[r] = b;
     }
     const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
     const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
-    dst[base + t] = sqrt(e0x * e0x + e0y * e0y) + sqrt(e1x * e1x + e1y * e1y);
+    dst[base + t] = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
   }
 }
 
@@ -217,15 +217,15 @@ __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
       double a = 0.0, b = 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        a += cam.p0[4 * r + c] * X[c];
-        b += cam.p1[4 * r + c] * X[c];
+        a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
+        b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
       }
       r0[r] = a;
       r1[r] = b;
     }
     const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
     const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
-    const double err = sqrt(e0x * e0x + e0y * e0y) + sqrt(e1x * e1x + e1y * e1y);
+    const double err = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
     const double s0 = det3_left(cam.p0) < 0 ? -1.0 : 1.0, s1 = det3_left(cam.p1) < 0 ? -1.0 : 1.0;
     const double n0 = cam.p0[2] * cam.p0[2] + cam.p0[6] * cam.p0[6] + cam.p0[10] * cam.p0[10];
     const double n1 = cam.p1[2] * cam.p1[2] + cam.p1[6] * cam.p1[6] + cam.p1[10] * cam.p1[10];
