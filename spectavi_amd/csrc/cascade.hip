@@ -61,19 +61,26 @@ __global__ void repack_dict_kernel(const float *__restrict__ dict, float *__rest
 }
 
 // ---------------------------------------------------------------------------------
-// 2/3. projections, codes, uint8 image.  Each lane owns two rows; the MC accumulators
-// of one table per row live in registers; the table's hyperplanes are staged in LDS
-// (128 dims at a time) and read by broadcast ds_read_b128 -- one LDS dword feeds
-// 64 lanes x 2 rows.  The projection of (row, bit) is ONE dim-ordered fp32 FMA chain.
+// 2/3. projections, codes, uint8 image.  A workgroup owns 512 rows, each lane two of
+// them.  Per 16-dim step the row tile is staged in LDS by coalesced 16-byte loads
+// (the uint8 image is written from the same registers), the hyperplanes of that step
+// are staged next to it and read by broadcast ds_read_b128 -- one LDS dword feeds
+// 64 lanes x 2 rows.  Accumulators of up to two tables x two rows stay in registers,
+// so float32 rows are read from HBM once.  The projection of (row, bit) is ONE
+// dim-ordered fp32 FMA chain (mirrored by the oracle).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2u8(float v) {
   return (uint32_t)((int)v + 128) & 0xFFu;  // trunc toward zero, wrap mod 256
 }
 
-constexpr int kProjRows = 2;     // rows per lane (register blocking against the LDS broadcast)
-constexpr int kProjChunk = 128;  // hyperplane dims staged in LDS at a time
+constexpr int kProjRows = 2;                 // rows per lane (amortises the hyperplane broadcast)
+constexpr int kProjTile = kThreads * kProjRows;  // rows per workgroup
+constexpr int kProjChunk = 16;               // dims staged per step (dim % 16 == 0 always)
+constexpr int kProjXStride = kProjChunk * 4 + 16;  // bytes per row in LDS: 80 -> conflict-free b128 reads
 
-template <int MC, bool IS_QUERY, int GMAX>
+// NT tables are accumulated per pass over the rows (NT*2*MC accumulators per lane), so with
+// the default n = 2 the float32 rows are read from HBM exactly once.
+template <int MC, int NT, bool IS_QUERY, int GMAX>
 __global__ __launch_bounds__(kThreads) void project_kernel(
     const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
     const float *__restrict__ dictp,     // [n][dim][MC]
@@ -81,106 +88,144 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
     uint32_t *__restrict__ masks,        // [n][nrows] (queries only)
     uint8_t *__restrict__ u8img) {       // [nrows][dim]
   constexpr int R = kProjRows;
-  __shared__ float4 sd[kProjChunk * MC / 4];  // hyperplanes [dims of the chunk][MC]
+  __shared__ __attribute__((aligned(16))) uint8_t xs[kProjTile * kProjXStride];  // row tile, 16 dims
+  __shared__ float4 sd[NT][kProjChunk * MC / 4];  // hyperplanes [table][dim of the chunk][MC]
   // accumulator start values: +0 for real hyperplanes, +inf for the zero-padded ones so
   // that they are never picked as "least confident" (their code bits are masked off)
   __shared__ float sinit[MC];
   const int t = threadIdx.x;
+  const int base = blockIdx.x * kProjTile;
   if (t < MC) sinit[t] = t < m ? 0.f : __builtin_inff();
   __syncthreads();
-  int r[R];
-  const float4 *src[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    r[k] = (blockIdx.x * R + k) * kThreads + t;
-    src[k] = reinterpret_cast<const float4 *>(rows + (size_t)min(r[k], nrows - 1) * dim);
-  }
-  for (int j = 0; j < n; ++j) {
-    float acc[R][MC];
+
+  for (int jt = 0; jt < n; jt += NT) {
+    float acc[NT][R][MC];
 #pragma unroll
     for (int b = 0; b < MC; ++b) {
       const float a0 = sinit[b];
 #pragma unroll
-      for (int k = 0; k < R; ++k) acc[k][b] = a0;
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc[tj][k][b] = a0;
     }
+    // register-prefetched staging: the global loads of step c0+16 are in flight while
+    // step c0 is being computed out of LDS
+    constexpr int NX = kProjTile * (kProjChunk / 4) / kThreads;           // row-tile vectors per lane
+    constexpr int ND = (NT * kProjChunk * MC / 4 + kThreads - 1) / kThreads;  // hyperplane vectors per lane
+    float4 px[NX], pd[ND];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int e = t + i * kThreads;
+        const int grow = base + (e >> 2);
+        px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow < nrows)
+          px[i] = *reinterpret_cast<const float4 *>(rows + (size_t)grow * dim + c0 + 4 * (e & 3));
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int e = t + i * kThreads;                 // [table of the pass][dim][MC/4]
+        const int tj = e / (kProjChunk * MC / 4), w = e % (kProjChunk * MC / 4);
+        pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tj < NT && jt + tj < n)
+          pd[i] = reinterpret_cast<const float4 *>(dictp + ((size_t)(jt + tj) * dim + c0) * MC)[w];
+      }
+    };
+    prefetch(0);
     for (int c0 = 0; c0 < dim; c0 += kProjChunk) {
-      const int cw = min(kProjChunk, dim - c0);  // multiple of 16
+      __syncthreads();  // everyone is done reading the previous step out of LDS
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int e = t + i * kThreads;
+        const int row = e >> 2, c = e & 3;
+        *reinterpret_cast<float4 *>(xs + row * kProjXStride + 16 * c) = px[i];
+        if (jt == 0 && base + row < nrows) {
+          const float4 v = px[i];
+          const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
+          *reinterpret_cast<uint32_t *>(u8img + (size_t)(base + row) * dim + c0 + 4 * c) = pk;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int e = t + i * kThreads;
+        if (e < NT * kProjChunk * MC / 4) (&sd[0][0])[e] = pd[i];
+      }
       __syncthreads();
-      const float4 *dsrc = reinterpret_cast<const float4 *>(dictp + ((size_t)j * dim + c0) * MC);
-      for (int e = t; e < cw * MC / 4; e += kThreads) sd[e] = dsrc[e];
-      __syncthreads();
-      for (int i0 = 0; i0 < cw; i0 += 4) {
+      if (c0 + kProjChunk < dim) prefetch(c0 + kProjChunk);
+#pragma unroll
+      for (int i0 = 0; i0 < kProjChunk; i0 += 4) {
         float4 xv[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) xv[k] = src[k][(c0 + i0) / 4];
-        if (j == 0) {
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            if (r[k] < nrows) {
-              const uint32_t pk = f2u8(xv[k].x) | (f2u8(xv[k].y) << 8) | (f2u8(xv[k].z) << 16) |
-                                  (f2u8(xv[k].w) << 24);
-              *reinterpret_cast<uint32_t *>(u8img + (size_t)r[k] * dim + c0 + i0) = pk;
-            }
-          }
-        }
+        for (int k = 0; k < R; ++k)
+          xv[k] = *reinterpret_cast<const float4 *>(xs + (t + k * kThreads) * kProjXStride + 4 * i0);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-          // all lanes read the same hyperplane row: LDS broadcast, MC/4 x ds_read_b128
-          float dv[MC];
 #pragma unroll
-          for (int b4 = 0; b4 < MC / 4; ++b4) {
-            const float4 d4 = sd[(i0 + ii) * (MC / 4) + b4];
-            dv[4 * b4 + 0] = d4.x;
-            dv[4 * b4 + 1] = d4.y;
-            dv[4 * b4 + 2] = d4.z;
-            dv[4 * b4 + 3] = d4.w;
-          }
+          for (int tj = 0; tj < NT; ++tj) {
+            // all lanes read the same hyperplane row: LDS broadcast, MC/4 x ds_read_b128
+            float dv[MC];
 #pragma unroll
-          for (int k = 0; k < R; ++k) {
-            const float xs = ii == 0 ? xv[k].x : (ii == 1 ? xv[k].y : (ii == 2 ? xv[k].z : xv[k].w));
+            for (int b4 = 0; b4 < MC / 4; ++b4) {
+              const float4 d4 = sd[tj][(i0 + ii) * (MC / 4) + b4];
+              dv[4 * b4 + 0] = d4.x;
+              dv[4 * b4 + 1] = d4.y;
+              dv[4 * b4 + 2] = d4.z;
+              dv[4 * b4 + 3] = d4.w;
+            }
 #pragma unroll
-            for (int b = 0; b < MC; ++b) acc[k][b] = __builtin_fmaf(xs, dv[b], acc[k][b]);
+            for (int k = 0; k < R; ++k) {
+              const float xsv =
+                  ii == 0 ? xv[k].x : (ii == 1 ? xv[k].y : (ii == 2 ? xv[k].z : xv[k].w));
+#pragma unroll
+              for (int b = 0; b < MC; ++b) acc[tj][k][b] = __builtin_fmaf(xsv, dv[b], acc[tj][k][b]);
+            }
           }
         }
       }
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      uint32_t code = 0;
+    for (int tj = 0; tj < NT; ++tj) {
+      const int j = jt + tj;
+      if (j >= n) break;
 #pragma unroll
-      for (int b = 0; b < MC; ++b) code |= (acc[k][b] >= 0.f ? 1u : 0u) << b;
-      code &= 0xFFFFFFFFu >> (32 - m);  // padded hyperplanes project to +0: drop their bits
-      if (r[k] < nrows) codes[(size_t)j * nrows + r[k]] = code;
-      if (IS_QUERY) {
-        // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
-        // order so a strict < keeps the lower bit on equal magnitude
-        float best[GMAX];
-        int bbit[GMAX];
+      for (int k = 0; k < R; ++k) {
+        const int r = base + t + k * kThreads;
+        uint32_t code = 0;
 #pragma unroll
-        for (int q = 0; q < GMAX; ++q) {
-          best[q] = __builtin_inff();
-          bbit[q] = -1;
-        }
-#pragma unroll
-        for (int b = 0; b < MC; ++b) {
-          float v = fabsf(acc[k][b]);  // +inf for padded hyperplanes: never inserted
-          int vb = b;
+        for (int b = 0; b < MC; ++b) code |= (acc[tj][k][b] >= 0.f ? 1u : 0u) << b;
+        code &= 0xFFFFFFFFu >> (32 - m);  // padded hyperplanes: drop their bits
+        if (r < nrows) codes[(size_t)j * nrows + r] = code;
+        if (IS_QUERY) {
+          // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
+          // order so a strict < keeps the lower bit on equal magnitude
+          float best[GMAX];
+          int bbit[GMAX];
 #pragma unroll
           for (int q = 0; q < GMAX; ++q) {
-            const bool lt = q < g && v < best[q];
-            const float tv = best[q];
-            const int tb = bbit[q];
-            best[q] = lt ? v : tv;
-            bbit[q] = lt ? vb : tb;
-            v = lt ? tv : v;
-            vb = lt ? tb : vb;
+            best[q] = __builtin_inff();
+            bbit[q] = -1;
           }
-        }
-        uint32_t mask = 0;
 #pragma unroll
-        for (int q = 0; q < GMAX; ++q)
-          if (q < g && bbit[q] >= 0) mask |= 1u << bbit[q];
-        if (r[k] < nrows) masks[(size_t)j * nrows + r[k]] = mask;
+          for (int b = 0; b < MC; ++b) {
+            float v = fabsf(acc[tj][k][b]);  // +inf for padded hyperplanes: never inserted
+            int vb = b;
+#pragma unroll
+            for (int q = 0; q < GMAX; ++q) {
+              const bool lt = q < g && v < best[q];
+              const float tv = best[q];
+              const int tb = bbit[q];
+              best[q] = lt ? v : tv;
+              bbit[q] = lt ? vb : tb;
+              v = lt ? tv : v;
+              vb = lt ? tb : vb;
+            }
+          }
+          uint32_t mask = 0;
+#pragma unroll
+          for (int q = 0; q < GMAX; ++q)
+            if (q < g && bbit[q] >= 0) mask |= 1u << bbit[q];
+          if (r < nrows) masks[(size_t)j * nrows + r] = mask;
+        }
       }
     }
   }
@@ -494,21 +539,28 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
                     const float *dictp, uint32_t *codes, uint32_t *masks, uint8_t *img,
                     hipStream_t stream) {
   if (nrows <= 0) return;
-  const int rows_per_block = kThreads * kProjRows;
-  const dim3 grid((nrows + rows_per_block - 1) / rows_per_block), block(kThreads);
+  const dim3 grid((nrows + kProjTile - 1) / kProjTile), block(kThreads);
   constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
-#define SPV_LAUNCH_PROJECT(MCV)                                                                 \
+  // two tables per pass while the accumulators fit (MC <= 24), else one
+#define SPV_LAUNCH_PROJECT(MCV, NTV)                                                           \
   if (g <= G1)                                                                                  \
-    hipLaunchKernelGGL((project_kernel<MCV, IS_QUERY, G1>), grid, block, 0, stream, rows, nrows, \
-                       dim, m, n, g, dictp, codes, masks, img);                                 \
+    hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G1>), grid, block, 0, stream, rows,  \
+                       nrows, dim, m, n, g, dictp, codes, masks, img);                          \
   else                                                                                          \
-    hipLaunchKernelGGL((project_kernel<MCV, IS_QUERY, G2>), grid, block, 0, stream, rows, nrows, \
-                       dim, m, n, g, dictp, codes, masks, img);
+    hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G2>), grid, block, 0, stream, rows,  \
+                       nrows, dim, m, n, g, dictp, codes, masks, img);
+  const bool two = n >= 2;
   switch (mc) {
-    case 8: SPV_LAUNCH_PROJECT(8) break;
-    case 16: SPV_LAUNCH_PROJECT(16) break;
-    case 24: SPV_LAUNCH_PROJECT(24) break;
-    default: SPV_LAUNCH_PROJECT(32) break;
+    case 8:
+      if (two) { SPV_LAUNCH_PROJECT(8, 2) } else { SPV_LAUNCH_PROJECT(8, 1) }
+      break;
+    case 16:
+      if (two) { SPV_LAUNCH_PROJECT(16, 2) } else { SPV_LAUNCH_PROJECT(16, 1) }
+      break;
+    case 24:
+      if (two) { SPV_LAUNCH_PROJECT(24, 2) } else { SPV_LAUNCH_PROJECT(24, 1) }
+      break;
+    default: SPV_LAUNCH_PROJECT(32, 1) break;
   }
 #undef SPV_LAUNCH_PROJECT
 }
