@@ -202,6 +202,30 @@ int spv_ratio_test_device(const uint64_t *d_idx, const void *d_dist, int dist_is
                           double min_ratio, int32_t *d_matches, int32_t *d_count, void *d_ws,
                           size_t ws_bytes, void *stream);
 
+/* SIFT table adapter: rows of 132 float32 = x, y, sigma, angle + 128 descriptor values that
+ * are uint8(512*d) stored as float (reference src/Sift.h:13,115-123) are split into
+ * geom float32[rows,4] and desc uint8[rows,128] (truncating cast).  Host form. */
+int spv_sift_split(const float *table, int rows, float *geom, uint8_t *desc);
+int spv_sift_split_device(const float *d_table, int rows, float *d_geom, uint8_t *d_desc,
+                          void *stream);
+/* (x, y, 1) float64 coordinates of both keypoints of every match (query row, database row)
+ * written by spv_ratio_test_device: d_x0[i] from d_geom_x[database row], d_x1[i] from
+ * d_geom_y[query row]; rows [0, *d_count) of the [capacity,3] outputs are written
+ * (reference example/ex01_essential_estimation.py:104-106). */
+int spv_gather_match_coords_device(const float *d_geom_x, const float *d_geom_y,
+                                   const int32_t *d_matches, const int32_t *d_count, int capacity,
+                                   double *d_x0, double *d_x1, void *stream);
+
+/* normalize_to_ubyte_and_multiple_16_dim (reference spectavi/feature.py:384-407) for a float32
+ * input, bit for bit what numpy computes: per-column de-mean (numpy's row-ordered float32 sum),
+ * divide by the per-column max-abs, x128, round half-to-even, clip to [-128,127], zero-pad the
+ * columns to dim16 = roundup(dim,16).  out_f32 float32[rows,dim16] and/or out_u8 =
+ * uint8(out + 128)[rows,dim16] (either may be NULL, not both). */
+int spv_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8);
+size_t spv_normalize_workspace_bytes(int dim);
+int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, uint8_t *d_out_u8,
+                         void *d_ws, size_t ws_bytes, void *stream);
+
 /* Device form of spv_dlt_score_hypotheses: P0 is a HOST pointer (12 doubles), d_P1s
  * double[nhyp,12], d_counts int32[nhyp] (zeroed by the call), d_mask uint8[nhyp,npt] or NULL. */
 int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,

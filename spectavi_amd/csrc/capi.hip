@@ -361,6 +361,46 @@ int host_ratio(const uint64_t *idx, const void *dist, int dist_is_float, int yro
   return SPV_OK;
 }
 
+int host_sift_split(const float *table, int rows, float *geom, uint8_t *desc) {
+  if (rows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  if (rows == 0) return SPV_OK;
+  if (!table || !geom || !desc) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  DevBuf dt, dg, dd;
+  SPV_TRY(dt.alloc((size_t)rows * 132 * sizeof(float)));
+  SPV_TRY(dg.alloc((size_t)rows * 4 * sizeof(float)));
+  SPV_TRY(dd.alloc((size_t)rows * 128));
+  hipStream_t st = nullptr;
+  SPV_HIP_CHECK(hipMemcpyAsync(dt.p, table, (size_t)rows * 132 * sizeof(float), hipMemcpyHostToDevice, st));
+  SPV_TRY(sift_split_run(dt.as<float>(), rows, dg.as<float>(), dd.as<uint8_t>(), st));
+  SPV_HIP_CHECK(hipMemcpyAsync(geom, dg.p, (size_t)rows * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(desc, dd.p, (size_t)rows * 128, hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
+int host_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8) {
+  if (rows < 0 || dim <= 0) return set_error(SPV_ERR_INVALID, "bad shape");
+  if (rows == 0) return SPV_OK;
+  if (!x || (!out_f32 && !out_u8)) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  const int dim16 = (dim + 15) / 16 * 16;
+  DevBuf dx, df, du, ws;
+  SPV_TRY(dx.alloc((size_t)rows * dim * sizeof(float)));
+  if (out_f32) SPV_TRY(df.alloc((size_t)rows * dim16 * sizeof(float)));
+  if (out_u8) SPV_TRY(du.alloc((size_t)rows * dim16));
+  SPV_TRY(ws.alloc(normalize_workspace_bytes(dim)));
+  hipStream_t st = nullptr;
+  SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, (size_t)rows * dim * sizeof(float), hipMemcpyHostToDevice, st));
+  SPV_TRY(normalize_run(dx.as<float>(), rows, dim, out_f32 ? df.as<float>() : nullptr,
+                        out_u8 ? du.as<unsigned char>() : nullptr, ws.p, normalize_workspace_bytes(dim), st));
+  if (out_f32)
+    SPV_HIP_CHECK(hipMemcpyAsync(out_f32, df.p, (size_t)rows * dim16 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (out_u8) SPV_HIP_CHECK(hipMemcpyAsync(out_u8, du.p, (size_t)rows * dim16, hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
 // Hyperplanes as the reference draws them (src/CascadingHashNn.h:86-100):
 // one std::mt19937 stream, std::normal_distribution<float>(0,1), table-major,
 // then dim (i), then bit (j).
@@ -562,6 +602,32 @@ int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const doubl
                         const double *xp, double *dst) {
   clear_error();
   return host_dlt(P0, P1, npt, x, xp, dst, false);
+}
+int spv_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8) {
+  clear_error();
+  return host_normalize(x, rows, dim, out_f32, out_u8);
+}
+size_t spv_normalize_workspace_bytes(int dim) { return dim <= 0 ? 0 : normalize_workspace_bytes(dim); }
+int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, uint8_t *d_out_u8,
+                         void *d_ws, size_t ws_bytes, void *stream) {
+  clear_error();
+  return normalize_run(d_x, rows, dim, d_out_f32, d_out_u8, d_ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+int spv_sift_split(const float *table, int rows, float *geom, uint8_t *desc) {
+  clear_error();
+  return host_sift_split(table, rows, geom, desc);
+}
+int spv_sift_split_device(const float *d_table, int rows, float *d_geom, uint8_t *d_desc,
+                          void *stream) {
+  clear_error();
+  return sift_split_run(d_table, rows, d_geom, d_desc, static_cast<hipStream_t>(stream));
+}
+int spv_gather_match_coords_device(const float *d_geom_x, const float *d_geom_y,
+                                   const int32_t *d_matches, const int32_t *d_count, int capacity,
+                                   double *d_x0, double *d_x1, void *stream) {
+  clear_error();
+  return gather_match_coords_run(d_geom_x, d_geom_y, d_matches, d_count, capacity, d_x0, d_x1,
+                                 static_cast<hipStream_t>(stream));
 }
 int spv_ratio_test(const uint64_t *idx, const void *dist, int dist_is_float, int yrows,
                    double min_ratio, int32_t *matches, int32_t *count) {

@@ -70,6 +70,16 @@ int ratio_run(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int 
               double min_ratio, int *d_matches, int *d_count, void *d_ws, size_t ws_bytes,
               hipStream_t stream);
 
+// ---- format adapters (adapter.hip) ---------------------------------------------------
+int sift_split_run(const float *d_table, int rows, float *d_geom, uint8_t *d_desc, hipStream_t stream);
+int gather_match_coords_run(const float *d_geom_x, const float *d_geom_y, const int *d_matches,
+                            const int *d_count, int capacity, double *d_x0, double *d_x1,
+                            hipStream_t stream);
+
+size_t normalize_workspace_bytes(int dim);
+int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigned char *d_out_u8,
+                  void *d_ws, size_t ws_bytes, hipStream_t stream);
+
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,
                   hipStream_t stream);

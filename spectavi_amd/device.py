@@ -169,6 +169,37 @@ def dlt_score_hypotheses(P0, P1s, x, xp, max_error, want_mask=False):
     return (counts, mask) if want_mask else counts
 
 
+clib.spv_sift_split_device.restype = ct.c_int
+clib.spv_sift_split_device.argtypes = [_vp, ct.c_int, _vp, _vp, _vp]
+clib.spv_gather_match_coords_device.restype = ct.c_int
+clib.spv_gather_match_coords_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, _vp, _vp, _vp]
+
+
+def split_sift_table(table):
+    """CUDA float32 [n,132] -> (geom float32 [n,4], desc uint8 [n,128])."""
+    _need(table, torch.float32, "table")
+    assert table.shape[1] == 132
+    n = table.shape[0]
+    geom = torch.empty((n, 4), dtype=torch.float32, device=table.device)
+    desc = torch.empty((n, 128), dtype=torch.uint8, device=table.device)
+    check(clib.spv_sift_split_device(table.data_ptr(), n, geom.data_ptr(), desc.data_ptr(), _stream()))
+    return geom, desc
+
+
+def match_coordinates(geom_x, geom_y, matches, count):
+    """Homogeneous float64 coordinates of matched keypoints: (x0 [cap,3] from geom_x[database row],
+    x1 [cap,3] from geom_y[query row]); rows [0, count) are valid."""
+    _need(geom_x, torch.float32, "geom_x")
+    _need(geom_y, torch.float32, "geom_y")
+    _need(matches, torch.int32, "matches")
+    cap = matches.shape[0]
+    x0 = torch.zeros((cap, 3), dtype=torch.float64, device=matches.device)
+    x1 = torch.zeros((cap, 3), dtype=torch.float64, device=matches.device)
+    check(clib.spv_gather_match_coords_device(geom_x.data_ptr(), geom_y.data_ptr(), matches.data_ptr(),
+                                              count.data_ptr(), cap, x0.data_ptr(), x1.data_ptr(), _stream()))
+    return x0, x1
+
+
 def profile_enable(on=True):
     """Bracket the hot kernels with HIP events on their launch stream."""
     clib.spv_profile_enable(1 if on else 0)

@@ -219,3 +219,49 @@ def ratio_test_matches(nn_idx, nn_dist, min_ratio):
     check(_spv_ratio_test(nn_idx, nn_dist.ctypes.data, is_float, yrows, float(min_ratio), matches,
                           ct.byref(count)))
     return matches[:count.value].copy()
+
+
+# ==================================================================================
+# SIFT table adapter (reference src/Sift.h:13,115-123: rows of 132 floats)
+# ==================================================================================
+_spv_sift_split = clib.spv_sift_split
+_spv_sift_split.restype = ct.c_int
+_spv_sift_split.argtypes = [ndpointer(ct.c_float, flags="C_CONTIGUOUS"), ct.c_int,
+                            ndpointer(ct.c_float, flags="C_CONTIGUOUS"),
+                            ndpointer(ct.c_ubyte, flags="C_CONTIGUOUS")]
+
+
+def split_sift_table(table):
+    """Split the reference's SIFT table (float32 [n,132] = x, y, sigma, angle + 128 descriptor
+    values that are uint8(512*d) stored as float) into (geometry float32 [n,4], descriptors
+    uint8 [n,128]) so that `nn_bruteforcel1k2` runs on the true 128-D bytes."""
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    if table.ndim != 2 or table.shape[1] != 132:
+        raise TypeError("SIFT table must be [n, 132]")
+    n = table.shape[0]
+    geom = np.empty((n, 4), np.float32)
+    desc = np.empty((n, 128), np.uint8)
+    check(_spv_sift_split(table, n, geom, desc))
+    return geom, desc
+
+
+# ==================================================================================
+# normalisation on device (same result as normalize_to_ubyte_and_multiple_16_dim above)
+# ==================================================================================
+_spv_normalize = clib.spv_normalize
+_spv_normalize.restype = ct.c_int
+_spv_normalize.argtypes = [ndpointer(ct.c_float, flags="C_CONTIGUOUS"), ct.c_int, ct.c_int, ct.c_void_p,
+                           ct.c_void_p]
+
+
+def normalize_to_ubyte_and_multiple_16_dim_gpu(x, want_ubyte=False):
+    """`normalize_to_ubyte_and_multiple_16_dim(x)` for a float32 `x`, computed on the GPU and
+    bit-identical to the numpy version; with `want_ubyte` also returns the
+    `(out + 128).astype('uint8')` image that `nn_bruteforcel1k2` takes."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, dim = x.shape
+    dim16 = int(np.ceil(dim / 16.) * 16)
+    out = np.empty((rows, dim16), np.float32)
+    u8 = np.empty((rows, dim16), np.uint8) if want_ubyte else None
+    check(_spv_normalize(x, rows, dim, out.ctypes.data, u8.ctypes.data if want_ubyte else None))
+    return (out, u8) if want_ubyte else out
