@@ -16,6 +16,32 @@ if not os.path.exists(lib_path):
         "libspectavi.so (HIP/gfx950) is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
         "or `make -C spectavi_amd/csrc`.  spectavi_amd has no CPU fallback.")
 
+
+
+def _preload_torch_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (+ libhsa-runtime64) under torch/lib; libspectavi.so is linked against the system ROCm.
+    If libspectavi.so initialises the system runtime first and torch is imported later, torch
+    brings up a second runtime and reports "No HIP GPUs are available".  When torch is
+    installed but not yet imported, load ITS runtime first so that both sides share it (the
+    loader resolves libspectavi's libamdhip64.so.7 dependency to the copy already in the
+    process).  SPECTAVI_NO_TORCH_PRELOAD=1 disables this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("SPECTAVI_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ct.CDLL(path, mode=ct.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall back to the system runtime
+
+
+_preload_torch_hip_runtime()
 clib = ct.cdll.LoadLibrary(lib_path)
 
 SPV_OK, SPV_ERR_INVALID, SPV_ERR_HIP, SPV_ERR_NOMEM = 0, 1, 2, 3

@@ -91,40 +91,90 @@ int gather_match_coords_run(const float *d_geom_x, const float *d_geom_y, const 
 //             numpy accumulates row by row in the input dtype -- verified against numpy 2.2]
 //   x0      = x - mean_c;  norm_c = max(max(x0), -min(x0))
 //   out     = clip(rint(x0 / norm_c * 128), -128, 127), zero-padded to a multiple of 16 columns
-// The column sums are inherently serial (float addition is not associative), so the statistics
-// kernel is one workgroup with one lane per column; everything else is parallel.  Optionally
+// The column sums are inherently serial in the rows (float addition is not associative), so the
+// statistics kernel parallelises over 16-column blocks only -- one workgroup each, all lanes
+// streaming row tiles into LDS, 16 lanes running the chains; everything else is parallel.  Optionally
 // also emits the +128 uint8 image the brute-force path takes
 // (example/ex01_essential_estimation.py:96-99).
 // ---------------------------------------------------------------------------------
 namespace spv {
 namespace {
 
-__global__ __launch_bounds__(1024) void column_stats_kernel(const float *__restrict__ x, int rows,
-                                                            int dim, float *__restrict__ stats) {
-  // stats[0][c] = mean, stats[1][c] = norm
-  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-    float s = 0.f, mx = -__builtin_inff(), mn = __builtin_inff();
-    int r = 0;
-    for (; r + 8 <= rows; r += 8) {
-      float v[8];
+constexpr int kStatCols = 16;   // columns per workgroup: one 64-byte sector of every row
+constexpr int kStatRows = 512;  // rows per LDS tile (double buffered: 2 x 32 KB)
+
+// One workgroup per block of 16 columns.  All 256 lanes stream the block's row tiles into
+// LDS (register-prefetched, one tile ahead); lanes 0..15 of wave 0 then run the serial
+// per-column chains over the tile in row order: s += v (float32, exactly numpy's order),
+// running max and min.  stats[0][c] = mean, stats[1][c] = max(max - mean, -(min - mean)).
+__global__ __launch_bounds__(256) void column_stats_kernel(const float *__restrict__ x, int rows,
+                                                           int dim, float *__restrict__ stats) {
+  __shared__ float tile[2][kStatRows * kStatCols];  // [row][column]
+  constexpr int NL = kStatRows * kStatCols / 256;  // 32 floats per lane per tile
+  const int t = threadIdx.x;
+  const int c0 = blockIdx.x * kStatCols;
+  const int ncol = min(kStatCols, dim - c0);
+  const int col = t & 15, rsub = t >> 4;  // lane -> (column, row within a group of 16 rows)
+  float pre[NL];
+  auto prefetch = [&](int row0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = x[(size_t)(r + k) * dim + c];
+    for (int i = 0; i < NL; ++i) {
+      const int r = row0 + rsub + 16 * i;
+      pre[i] = (r < rows && col < ncol) ? x[(size_t)r * dim + c0 + col] : 0.f;
+    }
+  };
+  // max / min are order-independent: every lane folds the values it loads itself; only the
+  // float32 sum needs the row-ordered serial chain (lanes 0..15)
+  float s = 0.f, mx = -__builtin_inff(), mn = __builtin_inff();
+  const int ntiles = (rows + kStatRows - 1) / kStatRows;
+  auto fold_minmax = [&](int row0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s += v[k];  // strictly in row order
-        mx = fmaxf(mx, v[k]);
-        mn = fminf(mn, v[k]);
+    for (int i = 0; i < NL; ++i) {
+      if (row0 + rsub + 16 * i < rows) {
+        mx = fmaxf(mx, pre[i]);
+        mn = fminf(mn, pre[i]);
       }
     }
-    for (; r < rows; ++r) {
-      const float v = x[(size_t)r * dim + c];
-      s += v;
-      mx = fmaxf(mx, v);
-      mn = fminf(mn, v);
+  };
+  if (ntiles > 0) prefetch(0);
+  for (int tl = 0; tl < ntiles; ++tl) {
+    float *buf = tile[tl & 1];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) buf[(rsub + 16 * i) * kStatCols + col] = pre[i];
+    fold_minmax(tl * kStatRows);
+    __syncthreads();  // tile tl is complete; tile tl-1's chain finished before its own barrier
+    if (tl + 1 < ntiles) prefetch((tl + 1) * kStatRows);
+    if (t < kStatCols) {
+      const int nr = min(kStatRows, rows - tl * kStatRows);
+      int r = 0;
+      for (; r + 16 <= nr; r += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = buf[(r + k) * kStatCols + t];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];  // strictly in row order
+      }
+      for (; r < nr; ++r) s += buf[r * kStatCols + t];
+    }
+    // the next iteration writes the OTHER buffer; this buffer is rewritten two iterations
+    // later, after the barrier of the next iteration, which the chain lanes reach only
+    // once they are done reading it
+  }
+  // combine the 16 row-groups' max / min per column
+  __syncthreads();
+  float *red = tile[0];
+  red[t] = mx;
+  red[256 + t] = mn;
+  __syncthreads();
+  if (t < ncol) {
+    float cmx = red[t], cmn = red[256 + t];
+    for (int k = 1; k < 16; ++k) {
+      cmx = fmaxf(cmx, red[16 * k + t]);
+      cmn = fminf(cmn, red[256 + 16 * k + t]);
     }
     const float mean = s / (float)rows;
-    stats[c] = mean;
-    stats[dim + c] = fmaxf(mx - mean, -(mn - mean));
+    stats[c0 + t] = mean;
+    stats[dim + c0 + t] = fmaxf(cmx - mean, -(cmn - mean));
   }
 }
 
@@ -162,8 +212,8 @@ int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigne
   float *stats = static_cast<float *>(d_ws);
   const int dim16 = (dim + 15) / 16 * 16;
   ProfScope prof("normalize", stream);
-  hipLaunchKernelGGL(column_stats_kernel, dim3(1), dim3(std::min(1024, (dim + 63) / 64 * 64)), 0, stream,
-                     d_x, rows, dim, stats);
+  hipLaunchKernelGGL(column_stats_kernel, dim3((dim + kStatCols - 1) / kStatCols), dim3(256), 0, stream, d_x,
+                     rows, dim, stats);
   hipLaunchKernelGGL(normalize_apply_kernel, dim3(2048), dim3(256), 0, stream, d_x, rows, dim, dim16, stats,
                      d_out_f32, d_out_u8);
   SPV_HIP_CHECK(hipGetLastError());

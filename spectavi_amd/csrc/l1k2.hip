@@ -350,9 +350,9 @@ __global__ __launch_bounds__(kThreads) void l1k2_merge_kernel(const uint64_t *__
                                                               int N, int S,
                                                               uint64_t *__restrict__ out_idx,
                                                               int32_t *__restrict__ out_dist) {
-  const int gt = blockIdx.x * kThreads + threadIdx.x;
-  const int query = gt / LPQ;
-  const int sub = gt % LPQ;
+  const long long gt = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int query = (int)(gt / LPQ);
+  const int sub = (int)(gt % LPQ);
   uint64_t a1 = kKey64None, a2 = kKey64None;
   if (query < N) {
     const uint64_t *p = part + (size_t)query * S * 2;

@@ -89,6 +89,12 @@ def main():
     assert np.allclose(tri, ref, rtol=0, atol=1e-9)
     np.savez_compressed(os.path.join(OUT, "dlt_1000.npz"), P0=P0, P1=P1, x=x, xp=xp, X=tri, err=err,
                         X_lapack=ref)
+    # the reference's own golden SIFT table (test/test_feature.py:38-41 loads it with np.loadtxt):
+    # a data file, stored here as float32 npz so that GPU tests have real-distribution descriptors
+    ref_table = "/root/reference/data/sift-test/sur-ogre.sift"
+    if os.path.exists(ref_table):
+        np.savez_compressed(os.path.join(OUT, "sift_sur_ogre_table.npz"),
+                            table=np.loadtxt(ref_table).astype(np.float32))
     print("golden fixtures written to", OUT)
 
 

@@ -103,6 +103,22 @@ def dlt(npt, steps, warmup):
         }), flush=True)
 
 
+def end_to_end():
+    """Host-pointer C-ABI path (pageable numpy in / numpy out): includes hipMalloc, H2D, D2H."""
+    n = 262144
+    rng = np.random.default_rng(0xdeadbeef)
+    x = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    y = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    feature.nn_bruteforcel1k2(x[:1024], y[:1024])
+    t0 = time.perf_counter()
+    feature.nn_bruteforcel1k2(x, y)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "nn_bruteforcel1k2 through the host-pointer C-ABI (PCIe-inclusive), pairs/s",
+                      "value": float(n) * n / dt, "unit": "pairs/s", "ms_per_step": dt * 1e3,
+                      "config": {"workload": "256k x 256k D=128, numpy in / numpy out"}, "dtype": "u8",
+                      "data": "synthetic"}), flush=True)
+
+
 def next_rows(steps, warmup):
     """The SURVEY 8(f) rows: RANSAC scoring, ratio test, normalisation, SIFT adapter."""
     dev = torch.device("cuda")
@@ -179,3 +195,4 @@ if __name__ == "__main__":
     cascade(a.rows, a.steps, a.warmup, planted=True)
     dlt(a.npt, a.steps, a.warmup)
     next_rows(a.steps, a.warmup)
+    end_to_end()

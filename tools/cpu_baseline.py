@@ -1,0 +1,51 @@
+"""CPU baseline table: the oracle (port of the reference loop nest) at
+nthreads = 1, 8 and all host threads on a bounded query sample against the full database,
+plus the serial DLT loop.  Run on the GPU box's host; prints JSON lines."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as o  # noqa: E402
+
+
+def l1k2(xrows, dim, threads, target_s=6.0):
+    rng = np.random.default_rng(0xdeadbeef)
+    x = rng.integers(0, 256, (xrows, dim), dtype=np.uint8)
+    y = rng.integers(0, 256, (4096 * 8, dim), dtype=np.uint8)
+    probe = 64 * threads
+    t0 = time.perf_counter()
+    o.nn_bruteforcel1k2(x, y[:probe], nthreads=threads)
+    dt = time.perf_counter() - t0
+    nq = int(min(len(y), max(probe, probe * target_s / dt)))
+    t0 = time.perf_counter()
+    o.nn_bruteforcel1k2(x, np.ascontiguousarray(y[:nq]), nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"path": "l1k2", "xrows": xrows, "queries_sampled": nq, "threads": threads, "seconds": dt,
+            "pairs_per_s": nq * xrows / dt}
+
+
+def dlt(npt=1_000_000):
+    rng = np.random.default_rng(1)
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((npt, 4))
+    x, xp = Xw @ P0.T, Xw @ P1.T
+    t0 = time.perf_counter()
+    o.dlt_triangulate(P0, P1, x, xp)
+    dt = time.perf_counter() - t0
+    return {"path": "dlt_triangulate (serial loop, as reference src/Spectavi.cpp:48-51)", "points": npt,
+            "threads": 1, "seconds": dt, "points_per_s": npt / dt}
+
+
+if __name__ == "__main__":
+    allc = o.max_threads()
+    cpu = [l for l in open("/proc/cpuinfo") if l.startswith("model name")]
+    print(json.dumps({"cpu": cpu[0].split(":", 1)[1].strip() if cpu else "?", "logical_cpus": os.cpu_count(),
+                      "omp_max_threads": allc}), flush=True)
+    for xrows in (1000, 262144):
+        for th in sorted({1, 8, allc}):
+            print(json.dumps(l1k2(xrows, 128, th)), flush=True)
+    print(json.dumps(dlt()), flush=True)
