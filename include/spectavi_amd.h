@@ -51,6 +51,9 @@ int spv_set_device(int device);
  * replicated, and each shard is written straight into its slice of the caller's
  * output by a host thread per device; a device may be listed more than once. */
 int spv_set_devices(const int *devices, int count);
+/* The host-pointer entry points keep freed device buffers in a per-device cache (up to
+ * 4 GiB) for reuse by later calls; this releases them. */
+void spv_release_cached_memory(void);
 /* Library version string. */
 const char *spv_version(void);
 

@@ -153,18 +153,84 @@ static int run_sharded(long long total, Fn fn) {
 namespace {
 
 // RAII device buffer for the host-pointer paths.
+// Per-device cache of freed device buffers for the host-pointer paths: repeated calls
+// (a front-end matching image pairs, RANSAC-style loops over dlt_triangulate) would
+// otherwise pay five hipMalloc/hipFree pairs each.  Grow-only up to kPoolCapBytes per
+// device; spv_release_cached_memory() empties it.  A buffer is returned to the pool only
+// after the call's stream has been synchronised, so reuse is safe without events.
+class DevicePool {
+ public:
+  static constexpr size_t kPoolCapBytes = (size_t)4 << 30;
+  void *acquire(int dev, size_t bytes, size_t *got) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto &fl = free_[dev];
+    size_t best = fl.size();
+    for (size_t i = 0; i < fl.size(); ++i)
+      if (fl[i].second >= bytes && fl[i].second <= 2 * bytes + 4096 &&
+          (best == fl.size() || fl[i].second < fl[best].second))
+        best = i;
+    if (best == fl.size()) return nullptr;
+    void *p = fl[best].first;
+    *got = fl[best].second;
+    held_[dev] -= fl[best].second;
+    fl.erase(fl.begin() + best);
+    return p;
+  }
+  void release(int dev, void *p, size_t bytes) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (held_[dev] + bytes <= kPoolCapBytes) {
+        free_[dev].emplace_back(p, bytes);
+        held_[dev] += bytes;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lk(mu_);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : free_) {
+      (void)hipSetDevice(kv.first);
+      for (auto &b : kv.second) (void)hipFree(b.first);
+      kv.second.clear();
+    }
+    held_.clear();
+    (void)hipSetDevice(cur);
+  }
+
+ private:
+  std::mutex mu_;
+  std::map<int, std::vector<std::pair<void *, size_t>>> free_;
+  std::map<int, size_t> held_;
+};
+DevicePool g_pool;
+
+// RAII device buffer for the host-pointer paths (allocated on the current device).
 struct DevBuf {
   void *p = nullptr;
+  size_t cap = 0;
+  int dev = 0;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) g_pool.release(dev, p, cap);
   }
   int alloc(size_t bytes) {
     if (bytes == 0) bytes = 16;
+    (void)hipGetDevice(&dev);
+    p = g_pool.acquire(dev, bytes, &cap);
+    if (p) return SPV_OK;
     hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      // the cache may be what is exhausting the device: drop it and retry once
+      g_pool.clear();
+      e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess) {
       p = nullptr;
       return set_error(SPV_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
+    cap = bytes;
     return SPV_OK;
   }
   template <typename T>
@@ -482,6 +548,8 @@ int spv_set_devices(const int *devices, int count) {
   g_device = devices[0];
   return SPV_OK;
 }
+
+void spv_release_cached_memory(void) { g_pool.clear(); }
 
 void spv_profile_enable(int on) { g_prof_on.store(on != 0); }
 

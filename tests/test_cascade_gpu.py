@@ -72,3 +72,25 @@ def test_reference_test_recall_bound(golden):
     nni, nnd = feature.nn_cascading_hash(x, y, m=8, n=16, g=5)
     gt_nni, _ = numpy_l1_top2((x + 128).astype(np.uint8), (y + 128).astype(np.uint8))
     assert np.sum(gt_nni != nni) <= 2 * round(.4 * 200)
+
+
+def test_randomized_parameters(oracle):
+    """Seeded random (rows, dim, m, n, g) settings, bit-exact vs the oracle incl. candidate counts."""
+    from spectavi_amd import feature
+    rng = np.random.default_rng(424242)
+    for _ in range(16):
+        dim = 16 * int(rng.integers(1, 13))
+        mr, nr = int(rng.integers(1, 3000)), int(rng.integers(1, 1200))
+        m = int(rng.integers(2, 14))
+        n = int(rng.integers(1, 5))
+        g = int(rng.integers(0, min(m, 5) + 1))
+        x = rng.integers(-128, 128, (mr, dim)).astype(np.float32)
+        y = rng.integers(-128, 128, (nr, dim)).astype(np.float32)
+        k = min(mr, nr) // 2
+        if k:
+            y[:k] = np.clip(x[rng.integers(0, mr, k)] + rng.integers(-2, 3, (k, dim)), -128, 127)
+        d = rng.standard_normal((n, dim, m)).astype(np.float32)
+        idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+        oidx, odist, oncand, _ = oracle.nn_cascading_hash(x, y, m, n, g, d)
+        assert np.array_equal(ncand, oncand), (mr, nr, dim, m, n, g)
+        assert np.array_equal(dist, odist) and np.array_equal(idx, oidx), (mr, nr, dim, m, n, g)

@@ -129,3 +129,50 @@ def test_full_size_properties_256k(oracle):
     oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y[sub].cpu().numpy(), nthreads=oracle.max_threads())
     assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
     assert np.array_equal(dist[sub].cpu().numpy(), odist)
+
+
+def test_randomized_shapes(oracle):
+    """40 seeded random shapes / widths / value ranges, host-pointer path, bit-exact vs the oracle."""
+    rng = np.random.default_rng(20261004)
+    for _ in range(40):
+        dim = 16 * int(rng.integers(1, 21))
+        m = int(rng.integers(0, 3000))
+        n = int(rng.integers(1, 1500))
+        hi = int(rng.choice([2, 4, 256]))
+        x = rng.integers(0, hi, (m, dim), dtype=np.uint8)
+        y = rng.integers(0, hi, (n, dim), dtype=np.uint8)
+        idx, dist = _raw(x, y)
+        oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+        assert np.array_equal(dist, odist), (m, n, dim, hi)
+        assert np.array_equal(idx, oidx), (m, n, dim, hi)
+
+
+def test_repeated_calls_reuse_cached_buffers(oracle):
+    """The host path caches device buffers between calls; results must not depend on it."""
+    import ctypes as ct
+    from spectavi_amd._lib import clib
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        m, n = int(rng.integers(10, 4000)), int(rng.integers(10, 4000))
+        x = rng.integers(0, 256, (m, 128), dtype=np.uint8)
+        y = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        idx, dist = _raw(x, y)
+        oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+        assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+        if k == 3:
+            clib.spv_release_cached_memory.restype = None
+            clib.spv_release_cached_memory()
+
+
+def test_workspace_too_small_is_an_error():
+    import torch
+    import ctypes as ct
+    from spectavi_amd._lib import clib, SPV_ERR_INVALID
+    from spectavi_amd import device  # noqa: F401  (declares argtypes)
+    x = torch.zeros((1000, 128), dtype=torch.uint8, device="cuda")
+    idx = torch.empty((1000, 2), dtype=torch.int64, device="cuda")
+    dist = torch.empty((1000, 2), dtype=torch.int32, device="cuda")
+    ws = torch.empty(256, dtype=torch.uint8, device="cuda")
+    st = clib.spv_l1k2_device(x.data_ptr(), x.data_ptr(), 1000, 1000, 128, idx.data_ptr(), dist.data_ptr(),
+                              ws.data_ptr(), 16, None)
+    assert st == SPV_ERR_INVALID and b"workspace" in clib.spv_last_error()
