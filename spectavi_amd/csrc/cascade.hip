@@ -36,6 +36,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace spv {
 namespace {
@@ -347,7 +348,9 @@ __device__ __forceinline__ uint32_t deposit_bits(uint32_t v, uint32_t mask) {
   return out;
 }
 
-template <int CPL>  // 16-byte chunks of the row per lane of an 8-lane group (dim <= 128*CPL)
+// CPL: 16-byte chunks of the row per lane of an 8-lane group (dim <= 128*CPL);
+// RU: rounds of 8 candidate rows in flight per wave
+template <int CPL, int RU>
 __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int m,
     int n, int g, int hb, const uint32_t *__restrict__ xcodes, const uint32_t *__restrict__ ysign,
@@ -383,7 +386,6 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     // `count` candidate indices in list[0..count).  Each 8-lane group takes one candidate
     // per round (8 rows = 8 full 128-byte lines per wave instruction); four rounds of row
     // gathers are issued before the first is consumed so the random-row latency overlaps.
-    constexpr int RU = 4;
     for (int c0 = 0; c0 < count; c0 += 8 * RU) {
       uint4 xv[RU][CPL];
       uint32_t cand[RU];
@@ -623,15 +625,25 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     return set_error(SPV_ERR_INVALID, "dim=%d > 512 is not supported by the cascade refine kernel",
                      dim);
   ProfScope prof_probe("cascade_probe_refine", stream);
-#define SPV_LAUNCH_PROBE(C)                                                                        \
-  hipLaunchKernelGGL((probe_refine_kernel<C>), grid, block, 0, stream, ux, uy, xrows, yrows, dim, \
+#define SPV_LAUNCH_PROBE(C, U)                                                                      \
+  hipLaunchKernelGGL((probe_refine_kernel<C, U>), grid, block, 0, stream, ux, uy, xrows, yrows, dim, \
                      m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand)
-  if (cpl == 1)
-    SPV_LAUNCH_PROBE(1);
-  else if (cpl == 2)
-    SPV_LAUNCH_PROBE(2);
-  else
-    SPV_LAUNCH_PROBE(4);
+  static const int ru_env = [] {
+    const char *e = getenv("SPECTAVI_CASCADE_RU");
+    return e ? atoi(e) : 0;
+  }();
+  if (cpl == 1) {
+    if (ru_env == 2)
+      SPV_LAUNCH_PROBE(1, 2);
+    else if (ru_env == 8)
+      SPV_LAUNCH_PROBE(1, 8);
+    else
+      SPV_LAUNCH_PROBE(1, 4);
+  } else if (cpl == 2) {
+    SPV_LAUNCH_PROBE(2, 4);
+  } else {
+    SPV_LAUNCH_PROBE(4, 2);
+  }
 #undef SPV_LAUNCH_PROBE
   SPV_HIP_CHECK(hipGetLastError());
   return SPV_OK;

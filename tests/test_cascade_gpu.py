@@ -94,3 +94,36 @@ def test_randomized_parameters(oracle):
         oidx, odist, oncand, _ = oracle.nn_cascading_hash(x, y, m, n, g, d)
         assert np.array_equal(ncand, oncand), (mr, nr, dim, m, n, g)
         assert np.array_equal(dist, odist) and np.array_equal(idx, oidx), (mr, nr, dim, m, n, g)
+
+
+def test_full_size_properties_1m(oracle):
+    """BASELINE config 3 (1M x 1M, m=17 n=2 g=2) resident in HBM: planted noisy copies are
+    recovered, reported distances are true L1 distances, and a 512-query subsample agrees
+    with the oracle (which hashes the full 1M-row database on the CPU) bit for bit."""
+    import torch
+    from spectavi_amd import device, feature
+    rows = 1_000_000
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = torch.randint(0, 256, (rows, 128), dtype=torch.uint8, device=dev, generator=g).float() - 128
+    perm = torch.randperm(rows, device=dev, generator=g)
+    y = torch.clamp(x[perm] + torch.randint(-3, 4, (rows, 128), device=dev, generator=g).float(), -128, 127)
+    m = feature.auto_hash_bit_rate(rows, rows)
+    assert m == 17
+    d_host = feature.generate_hash_dict(0x5eed, 128, m, 2)
+    idx, dist, ncand = device.cascade(x, y, torch.from_numpy(d_host).to(dev), g=2, want_ncand=True)
+    torch.cuda.synchronize()
+    assert float((idx[:, 0] == perm).float().mean()) > 0.999
+    assert bool((dist[:, 0] <= dist[:, 1]).all())
+    sel = torch.arange(0, rows, 997, device=dev)
+    ok = idx[sel, 1] >= 0
+    for c in range(2):
+        rows_c = idx[sel, c].clamp(min=0)
+        dtrue = ((x[rows_c] + 128).to(torch.int32) - (y[sel] + 128).to(torch.int32)).abs().sum(1).float()
+        good = ok if c == 1 else torch.ones_like(ok)
+        assert bool((dtrue[good] == dist[sel, c][good]).all())
+    sub = np.arange(0, rows, rows // 512)[:512]
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(x.cpu().numpy(), y[sub].cpu().numpy(), m, 2, 2, d_host)
+    assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist[sub].cpu().numpy(), odist)
+    assert np.array_equal(ncand[sub].cpu().numpy(), oncand)
