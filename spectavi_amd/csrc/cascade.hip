@@ -355,13 +355,17 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int m,
     int n, int g, int hb, const uint32_t *__restrict__ xcodes, const uint32_t *__restrict__ ysign,
     const uint32_t *__restrict__ ymask, const uint32_t *__restrict__ bstart,
-    const uint32_t *__restrict__ order, uint64_t *__restrict__ out_idx,
-    float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
+    const uint32_t *__restrict__ order, const uint8_t *__restrict__ only_flagged,
+    uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
   __shared__ uint32_t lists[kThreads / 64][kListCap];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int query = blockIdx.x * (kThreads / 64) + wave;
-  if (query >= N) return;  // whole wave exits together
+  // grid-stride over queries: one launch shape serves both the full pass (grid = N/4
+  // workgroups, one query per wave) and the overflow pass (a few thousand workgroups that
+  // skip everything the group kernel already answered)
+  const int nwaves = gridDim.x * (kThreads / 64);
+  for (int query = blockIdx.x * (kThreads / 64) + wave; query < N; query += nwaves) {
+  if (only_flagged && !only_flagged[query]) continue;
   uint32_t *list = lists[wave];
   const int sub = lane & 7;    // chunk owner inside the 8-lane group
   const int grp = lane >> 3;   // candidate slot 0..7
@@ -432,8 +436,8 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     uint32_t s = 0, len = 0, pcode = 0;
     int tj = 0;
     if (p < nprobe) {
-      tj = p / nvar;
-      const uint32_t var = (uint32_t)(p % nvar);
+      tj = p >> g;
+      const uint32_t var = (uint32_t)(p & (nvar - 1));
       const uint32_t sg = ysign[(size_t)tj * N + query];
       const uint32_t mk = ymask[(size_t)tj * N + query];
       pcode = (sg & ~mk) | deposit_bits(var, mk);
@@ -504,12 +508,152 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     out_dist[2 * (size_t)query + 1] = n2 ? 2147483648.0f : (float)(uint32_t)(k2 >> 32);
     if (out_ncand) out_ncand[query] = visited;
   }
+  }  // query loop
+}
+
+
+// ---------------------------------------------------------------------------------
+// 7b. group-per-query probe + refine: one 8-lane group per query, 8 queries per wave,
+// 32 per workgroup.  The one-wave-per-query kernel above spends ~1100 wave instructions
+// per query and is issue-bound; here every wave instruction serves 8 queries: lane s of a
+// group owns probe s of each pass of 8 probes (the default n * 2^g is exactly 8), the
+// group copies its buckets into a private LDS list, and in every round each group
+// gathers ONE candidate row (8 lanes x 16 bytes = one 128-byte line, 8 different
+// queries' lines per wave instruction), v_sad_u8 + DPP sum, branch-free top-2.  All 8
+// lanes of a group hold the same keys, so no cross-lane merge is needed at the end.
+// A query whose pass needs more than kGroupCap list entries is flagged and redone by the
+// wave-per-query kernel (second launch, flagged queries only).
+// ---------------------------------------------------------------------------------
+constexpr int kGroupCap = 224;  // candidate indices per group per pass (32 groups -> 28 KB LDS)
+
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+template <int CPL, int RU>
+__global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
+    const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int n,
+    int g, int hb, const uint32_t *__restrict__ ysign, const uint32_t *__restrict__ ymask,
+    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ order,
+    uint8_t *__restrict__ overflow, uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
+    int32_t *__restrict__ out_ncand) {
+  __shared__ uint32_t lists[kThreads / 8][kGroupCap];
+  const int t = threadIdx.x;
+  const int sub = t & 7;
+  const int query = blockIdx.x * (kThreads / 8) + (t >> 3);
+  const bool valid = query < N;
+  const int q = valid ? query : N - 1;  // keep every lane alive for the cross-lane ops
+  uint32_t *list = lists[t >> 3];
+  const int nchunk = dim / 16;
+  const uint32_t nb = 1u << hb;
+  const uint32_t hbmask = nb - 1;
+  const int nvar = 1 << g;
+  const int nprobe = n << g;
+
+  uint4 qv[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = sub + 8 * c;
+    qv[c] = ch < nchunk ? *reinterpret_cast<const uint4 *>(uy + (size_t)q * dim + 16 * ch)
+                        : make_uint4(0, 0, 0, 0);
+  }
+  uint64_t k1 = kNone64, k2 = kNone64;
+  int visited = 0;
+  bool ovf = false;
+
+  for (int p0 = 0; p0 < nprobe; p0 += 8) {
+    // lane `sub` owns probe p0 + sub of this pass
+    const int p = p0 + sub;
+    uint32_t s = 0, len = 0;
+    int tj = 0;
+    if (p < nprobe) {
+      tj = p >> g;
+      const uint32_t var = (uint32_t)(p & (nvar - 1));
+      const uint32_t sg = ysign[(size_t)tj * N + q];
+      const uint32_t mk = ymask[(size_t)tj * N + q];
+      const uint32_t pcode = (sg & ~mk) | deposit_bits(var, mk);
+      const uint32_t *bs = bstart + (size_t)tj * (nb + 1) + (pcode & hbmask);
+      s = bs[0];
+      len = bs[1] - s;
+    }
+    // exclusive offsets of the 8 buckets inside the group's list
+    uint32_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 8);
+      if (sub >= d) incl += o;
+    }
+    const uint32_t total = __shfl(incl, 7, 8);
+    const uint32_t excl = incl - len;
+    if (total > (uint32_t)kGroupCap) ovf = true;
+    const uint32_t T = ovf ? 0u : total;
+    // copy the buckets: bucket b is broadcast from lane b, all 8 lanes copy it
+    for (int b = 0; b < 8; ++b) {
+      const uint32_t bl = ovf ? 0u : __shfl(len, b, 8);
+      const uint32_t bs_ = __shfl(s, b, 8);
+      const uint32_t bo = __shfl(excl, b, 8);
+      const int bj = __shfl(tj, b, 8);
+      const uint32_t *src = order + (size_t)bj * M + bs_;
+      for (uint32_t e = sub; e < bl; e += 8) list[bo + e] = src[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    visited += (int)T;
+    // rounds: one candidate row per group per round, RU rounds in flight
+    for (uint32_t f0 = 0; __any(f0 < T); f0 += RU) {
+      uint4 xv[RU][CPL];
+      uint32_t cand[RU];
+      bool live[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        live[u] = f0 + u < T;
+        cand[u] = list[live[u] ? f0 + u : 0];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int ch = sub + 8 * c;
+          xv[u][c] = make_uint4(0, 0, 0, 0);
+          if (live[u] && ch < nchunk)
+            xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)cand[u] * dim + 16 * ch);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          d = sad_u8(qv[c].x, xv[u][c].x, d);
+          d = sad_u8(qv[c].y, xv[u][c].y, d);
+          d = sad_u8(qv[c].z, xv[u][c].z, d);
+          d = sad_u8(qv[c].w, xv[u][c].w, d);
+        }
+        d = group8_sum(d);
+        // branch-free insertion of a key that may repeat (same row reached via another table)
+        uint64_t k = ((uint64_t)d << 32) | cand[u];
+        const bool skip = !live[u] || k == k1 || k == k2;
+        k = skip ? kNone64 : k;
+        const uint64_t hi = max_u64(k, k1);
+        k1 = min_u64(k, k1);
+        k2 = min_u64(hi, k2);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (valid && sub == 0) {
+    overflow[query] = ovf ? 1 : 0;
+    if (!ovf) {
+      const bool n1 = k1 == kNone64, n2 = k2 == kNone64;
+      out_idx[2 * (size_t)query + 0] = n1 ? ~0ull : (k1 & 0xFFFFFFFFull);
+      out_idx[2 * (size_t)query + 1] = n2 ? ~0ull : (k2 & 0xFFFFFFFFull);
+      out_dist[2 * (size_t)query + 0] = n1 ? 2147483648.0f : (float)(uint32_t)(k1 >> 32);
+      out_dist[2 * (size_t)query + 1] = n2 ? 2147483648.0f : (float)(uint32_t)(k2 >> 32);
+      if (out_ncand) out_ncand[query] = visited;
+    }
+  }
 }
 
 struct CascadeLayout {
   int mc, hb;
   size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart, off_cursor,
-      off_order, total;
+      off_order, off_ovf, total;
 };
 
 CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
@@ -532,6 +676,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   L.off_bstart = take((size_t)n * nb1 * sizeof(uint32_t));
   L.off_cursor = take((size_t)n * nb1 * sizeof(uint32_t));
   L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
+  L.off_ovf = take((size_t)yrows);
   L.total = off;
   return L;
 }
@@ -594,6 +739,7 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   uint32_t *bstart = reinterpret_cast<uint32_t *>(ws + L.off_bstart);
   uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.off_cursor);
   uint32_t *order = reinterpret_cast<uint32_t *>(ws + L.off_order);
+  uint8_t *ovf = ws + L.off_ovf;
   const int nb = 1 << L.hb;
   const uint32_t hbmask = (uint32_t)nb - 1;
 
@@ -625,9 +771,31 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     return set_error(SPV_ERR_INVALID, "dim=%d > 512 is not supported by the cascade refine kernel",
                      dim);
   ProfScope prof_probe("cascade_probe_refine", stream);
-#define SPV_LAUNCH_PROBE(C, U)                                                                      \
-  hipLaunchKernelGGL((probe_refine_kernel<C, U>), grid, block, 0, stream, ux, uy, xrows, yrows, dim, \
-                     m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand)
+  // group-per-query kernel first (unless the full-code check is needed: m > bucket bits);
+  // the wave-per-query kernel then redoes only the queries it flagged as overflowing
+  static const bool group_env = [] {
+    const char *e = getenv("SPECTAVI_CASCADE_GROUP");
+    return !(e && e[0] == '0');
+  }();
+  const bool use_group = group_env && m <= L.hb && cpl <= 2;
+  const uint8_t *flagged = nullptr;
+  if (use_group) {
+    const dim3 ggrid((yrows + kThreads / 8 - 1) / (kThreads / 8));
+    if (cpl == 1)
+      hipLaunchKernelGGL((probe_refine_group_kernel<1, 4>), ggrid, block, 0, stream, ux, uy, xrows,
+                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, ovf, d_idx, d_dist,
+                         d_ncand);
+    else
+      hipLaunchKernelGGL((probe_refine_group_kernel<2, 2>), ggrid, block, 0, stream, ux, uy, xrows,
+                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, ovf, d_idx, d_dist,
+                         d_ncand);
+    flagged = ovf;
+  }
+  const dim3 pgrid(flagged ? std::min<unsigned>(grid.x, 4096u) : grid.x);
+#define SPV_LAUNCH_PROBE(C, U)                                                                       \
+  hipLaunchKernelGGL((probe_refine_kernel<C, U>), pgrid, block, 0, stream, ux, uy, xrows, yrows, dim, \
+                     m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, flagged, d_idx, d_dist,    \
+                     d_ncand)
   static const int ru_env = [] {
     const char *e = getenv("SPECTAVI_CASCADE_RU");
     return e ? atoi(e) : 0;
