@@ -5,26 +5,29 @@
 // unordered_map<code, list<idx>> buckets on the host, and per query unions the
 // buckets of 2^g multi-probe codes per table into an unordered_set that feeds
 // the L1 brute force as a candidate filter.  Here everything is flat arrays in
-// HBM and seven kernels:
+// HBM and these kernels:
 //
 //   1 repack_dict     dict[n][dim][m] -> dictp[n][dim][MC], MC = roundup(m,8), zero padded
 //   2 project<false>  database rows: n*m random-hyperplane projections as a
 //                     dim-ordered fp32 FMA chain (the oracle runs the identical
 //                     chain, so sign bits match bit for bit), sign-packed codes
-//                     (bit b set iff proj >= 0, src/CascadingHashNn.h:102-111) and
-//                     the uint8 refine image  u8 = (int(trunc v) + 128) & 255
-//                     (src/CascadingHashNn.h:236-239)
+//                     (bit b set iff proj >= 0, src/CascadingHashNn.h:102-111), the
+//                     uint8 refine image  u8 = (int(trunc v) + 128) & 255
+//                     (src/CascadingHashNn.h:236-239) and the bucket histogram
 //   3 project<true>   query rows: sign code + mask of the g least-confident bits
 //                     (smallest (|proj|, bit) pairs, src/CascadingHashNn.h:150-160)
 //                     + uint8 image
-//   4 bucket_count / 5 bucket_scan / 6 bucket_fill   counting sort of database
+//   4 bucket_segsum / segscan / scan, 5 bucket_fill   counting sort of database
 //                     indices by bucket = code & (2^HB - 1), per table
-//   7 probe_refine    one wave per query: 2^g probe codes per table
-//                     (src/CascadingHashNn.h:170-179) -> bucket ranges -> candidate
-//                     list in LDS -> 8 lanes gather one 128-byte candidate row each
-//                     (8 rows per wave instruction), v_sad_u8 + DPP reduce, running
-//                     two smallest (dist, idx) keys per lane group, then a
-//                     wavefront-shuffle argmin-2 merge over the 8 groups.
+//   6 probe_refine_group   one 8-lane group per query (8 queries per wave): 2^g probe
+//                     codes per table (src/CascadingHashNn.h:170-179) -> bucket ranges ->
+//                     the group's candidate list in LDS -> per round each group gathers
+//                     one 128-byte candidate row (8 different queries' lines per wave
+//                     instruction), v_sad_u8 + DPP reduce, branch-free two smallest
+//                     (dist, idx) keys
+//   7 probe_refine    one wave per query, any candidate count / full-code check
+//                     (m > 22): redoes the queries kernel 6 flagged as overflowing, or
+//                     everything when kernel 6 does not apply
 //
 // Candidate semantics (closed form of filter_potential_neighbours, :208-227):
 // database row k is a candidate of query i iff for some table j
@@ -87,9 +90,12 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
     const float *__restrict__ dictp,     // [n][dim][MC]
     uint32_t *__restrict__ codes,        // [n][nrows] sign codes
     uint32_t *__restrict__ masks,        // [n][nrows] (queries only)
-    uint8_t *__restrict__ u8img) {       // [nrows][dim]
+    uint8_t *__restrict__ u8img,         // [nrows][dim]
+    uint32_t *__restrict__ counts,       // [n][nb+1] bucket histogram (database only, may be NULL)
+    uint32_t hbmask, int nb) {
   constexpr int R = kProjRows;
   __shared__ __attribute__((aligned(16))) uint8_t xs[kProjTile * kProjXStride];  // row tile, 16 dims
+  __shared__ __attribute__((aligned(16))) uint8_t u8s[kProjTile * 64];  // uint8 image, four steps
   __shared__ float4 sd[NT][kProjChunk * MC / 4];  // hyperplanes [table][dim of the chunk][MC]
   // accumulator start values: +0 for real hyperplanes, +inf for the zero-padded ones so
   // that they are never picked as "least confident" (their code bits are masked off)
@@ -140,10 +146,12 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
         const int e = t + i * kThreads;
         const int row = e >> 2, c = e & 3;
         *reinterpret_cast<float4 *>(xs + row * kProjXStride + 16 * c) = px[i];
-        if (jt == 0 && base + row < nrows) {
+        if (jt == 0) {
+          // uint8 image: four 16-dim steps are collected per row in LDS (64 bytes per row,
+          // unpadded: 16*e addressing) and flushed below as 64-byte runs = full sectors
           const float4 v = px[i];
           const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
-          *reinterpret_cast<uint32_t *>(u8img + (size_t)(base + row) * dim + c0 + 4 * c) = pk;
+          *reinterpret_cast<uint32_t *>(u8s + row * 64 + ((c0 >> 4) & 3) * 16 + 4 * c) = pk;
         }
       }
 #pragma unroll
@@ -152,6 +160,18 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
         if (e < NT * kProjChunk * MC / 4) (&sd[0][0])[e] = pd[i];
       }
       __syncthreads();
+      if (jt == 0 && ((((c0 >> 4) & 3) == 3) || c0 + kProjChunk >= dim)) {
+        const int ngrp = ((c0 >> 4) & 3) + 1;
+        const int col0 = c0 - (ngrp - 1) * kProjChunk;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const int e = t + i * kThreads;
+          const int row = e >> 2, q = e & 3;
+          if (q < ngrp && base + row < nrows)
+            *reinterpret_cast<uint4 *>(u8img + (size_t)(base + row) * dim + col0 + 16 * q) =
+                *reinterpret_cast<const uint4 *>(u8s + 16 * e);
+        }
+      }
       if (c0 + kProjChunk < dim) prefetch(c0 + kProjChunk);
 #pragma unroll
       for (int i0 = 0; i0 < kProjChunk; i0 += 4) {
@@ -195,7 +215,11 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
 #pragma unroll
         for (int b = 0; b < MC; ++b) code |= (acc[tj][k][b] >= 0.f ? 1u : 0u) << b;
         code &= 0xFFFFFFFFu >> (32 - m);  // padded hyperplanes: drop their bits
-        if (r < nrows) codes[(size_t)j * nrows + r] = code;
+        if (r < nrows) {
+          codes[(size_t)j * nrows + r] = code;
+          // database rows: bucket histogram for the counting sort, fused here
+          if (!IS_QUERY && counts) atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
+        }
         if (IS_QUERY) {
           // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
           // order so a strict < keeps the lower bit on equal magnitude
@@ -235,30 +259,38 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
 // ---------------------------------------------------------------------------------
 // 4-6. counting sort of database indices by bucket, per table
 // ---------------------------------------------------------------------------------
-__global__ void bucket_count_kernel(const uint32_t *__restrict__ codes, int M, int n,
-                                    uint32_t hbmask, int nb, uint32_t *__restrict__ counts) {
-  const size_t total = (size_t)n * M;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
-       e += (size_t)gridDim.x * blockDim.x) {
-    const int j = (int)(e / M);
-    atomicAdd(&counts[(size_t)j * (nb + 1) + (codes[e] & hbmask)], 1u);
-  }
+// Exclusive scan of counts[j][0..nb] in place, three small kernels: per-segment sums
+// (1024 entries each), a scan of the segment sums (one workgroup per table), and the
+// segment-local scans with the carried offset.  cursor[j][b] receives a copy of the start
+// offsets for the fill pass.
+constexpr int kScanSeg = 1024;
+
+__global__ __launch_bounds__(256) void bucket_segsum_kernel(const uint32_t *__restrict__ counts,
+                                                            int nb, int nseg,
+                                                            uint32_t *__restrict__ segsum) {
+  __shared__ uint32_t wsum[4];
+  const int j = blockIdx.y, seg = blockIdx.x;
+  const uint32_t *c = counts + (size_t)j * (nb + 1);
+  uint32_t v = 0;
+  for (int e = seg * kScanSeg + threadIdx.x; e < min((seg + 1) * kScanSeg, nb + 1); e += 256) v += c[e];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) segsum[(size_t)j * nseg + seg] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// Exclusive scan of counts[j][0..nb] in place (one 1024-thread block per table);
-// cursor[j][b] receives a copy of the start offsets for the fill pass.
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict__ counts,
-                                                           uint32_t *__restrict__ cursor, int nb) {
+// in-place exclusive scan of segsum[j][0..nseg) (nseg <= 4097 for 2^22 buckets)
+__global__ __launch_bounds__(1024) void bucket_segscan_kernel(uint32_t *__restrict__ segsum, int nseg) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry;
-  uint32_t *c = counts + (size_t)blockIdx.x * (nb + 1);
-  uint32_t *cu = cursor + (size_t)blockIdx.x * (nb + 1);
+  uint32_t *c = segsum + (size_t)blockIdx.x * nseg;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base <= nb; base += 1024) {
+  for (int base = 0; base < nseg; base += 1024) {
     const int e = base + t;
-    const uint32_t v = e <= nb ? c[e] : 0u;
+    const uint32_t v = e < nseg ? c[e] : 0u;
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -270,13 +302,38 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict_
     uint32_t woff = 0;
     for (int k = 0; k < w; ++k) woff += wsum[k];
     const uint32_t excl = carry + woff + incl - v;
-    if (e <= nb) {
-      c[e] = excl;
-      cu[e] = excl;
-    }
+    if (e < nseg) c[e] = excl;
     __syncthreads();
     if (t == 1023) carry = excl + v;
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict__ counts,
+                                                           uint32_t *__restrict__ cursor, int nb,
+                                                           int nseg,
+                                                           const uint32_t *__restrict__ segoff) {
+  __shared__ uint32_t wsum[16];
+  const int j = blockIdx.y, seg = blockIdx.x;
+  uint32_t *c = counts + (size_t)j * (nb + 1);
+  uint32_t *cu = cursor + (size_t)j * (nb + 1);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int e = seg * kScanSeg + t;
+  const uint32_t v = e <= nb ? c[e] : 0u;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t woff = segoff[(size_t)j * nseg + seg];
+  for (int k = 0; k < w; ++k) woff += wsum[k];
+  const uint32_t excl = woff + incl - v;
+  if (e <= nb) {
+    c[e] = excl;
+    cu[e] = excl;
   }
 }
 
@@ -360,12 +417,9 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
   __shared__ uint32_t lists[kThreads / 64][kListCap];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  // grid-stride over queries: one launch shape serves both the full pass (grid = N/4
-  // workgroups, one query per wave) and the overflow pass (a few thousand workgroups that
-  // skip everything the group kernel already answered)
-  const int nwaves = gridDim.x * (kThreads / 64);
-  for (int query = blockIdx.x * (kThreads / 64) + wave; query < N; query += nwaves) {
-  if (only_flagged && !only_flagged[query]) continue;
+  // one query per wave; the driver loop at the end of the kernel serves both the full pass
+  // (grid = N/4 workgroups) and the overflow pass (flagged queries only)
+  auto process_query = [&](const int query) {
   uint32_t *list = lists[wave];
   const int sub = lane & 7;    // chunk owner inside the 8-lane group
   const int grp = lane >> 3;   // candidate slot 0..7
@@ -508,7 +562,24 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     out_dist[2 * (size_t)query + 1] = n2 ? 2147483648.0f : (float)(uint32_t)(k2 >> 32);
     if (out_ncand) out_ncand[query] = visited;
   }
-  }  // query loop
+  };  // process_query
+
+  const int nwaves = gridDim.x * (kThreads / 64);
+  const int wave_id = blockIdx.x * (kThreads / 64) + wave;
+  if (only_flagged) {
+    // overflow pass: each wave scans 64 flags at a time and redoes only the flagged queries
+    for (int q0 = wave_id * 64; q0 < N; q0 += nwaves * 64) {
+      const bool f = q0 + lane < N && only_flagged[q0 + lane] != 0;
+      unsigned long long todo = __ballot(f);
+      while (todo) {
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        process_query(q0 + b);
+      }
+    }
+  } else {
+    for (int query = wave_id; query < N; query += nwaves) process_query(query);
+  }
 }
 
 
@@ -524,7 +595,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
 // A query whose pass needs more than kGroupCap list entries is flagged and redone by the
 // wave-per-query kernel (second launch, flagged queries only).
 // ---------------------------------------------------------------------------------
-constexpr int kGroupCap = 224;  // candidate indices per group per pass (32 groups -> 28 KB LDS)
+constexpr int kGroupCap = 288;  // candidate indices per group per pass (32 groups -> 36 KB LDS)
 
 __device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
@@ -653,7 +724,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
 struct CascadeLayout {
   int mc, hb;
   size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart, off_cursor,
-      off_order, off_ovf, total;
+      off_order, off_ovf, off_segsum, total;
 };
 
 CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
@@ -677,6 +748,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   L.off_cursor = take((size_t)n * nb1 * sizeof(uint32_t));
   L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_ovf = take((size_t)yrows);
+  L.off_segsum = take((size_t)n * ((nb1 + kScanSeg - 1) / kScanSeg) * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -684,7 +756,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
 template <bool IS_QUERY>
 void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m, int n,
                     const float *dictp, uint32_t *codes, uint32_t *masks, uint8_t *img,
-                    hipStream_t stream) {
+                    uint32_t *counts, uint32_t hbmask, int nb, hipStream_t stream) {
   if (nrows <= 0) return;
   const dim3 grid((nrows + kProjTile - 1) / kProjTile), block(kThreads);
   constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
@@ -692,10 +764,10 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
 #define SPV_LAUNCH_PROJECT(MCV, NTV)                                                           \
   if (g <= G1)                                                                                  \
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G1>), grid, block, 0, stream, rows,  \
-                       nrows, dim, m, n, g, dictp, codes, masks, img);                          \
+                       nrows, dim, m, n, g, dictp, codes, masks, img, counts, hbmask, nb);      \
   else                                                                                          \
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G2>), grid, block, 0, stream, rows,  \
-                       nrows, dim, m, n, g, dictp, codes, masks, img);
+                       nrows, dim, m, n, g, dictp, codes, masks, img, counts, hbmask, nb);
   const bool two = n >= 2;
   switch (mc) {
     case 8:
@@ -743,22 +815,28 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   const int nb = 1 << L.hb;
   const uint32_t hbmask = (uint32_t)nb - 1;
 
+  SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
   {
   ProfScope prof("cascade_project", stream);
   hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
                      m, L.mc);
-  launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, stream);
-  launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, stream);
+  launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, bstart, hbmask, nb,
+                        stream);
+  launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, nullptr, hbmask, nb,
+                       stream);
   }
   SPV_HIP_CHECK(hipGetLastError());
 
   {
   ProfScope prof("cascade_buckets", stream);
-  SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
-  if (xrows > 0)
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, xrows, n,
-                       hbmask, nb, bstart);
-  hipLaunchKernelGGL(bucket_scan_kernel, dim3(n), dim3(1024), 0, stream, bstart, cursor, nb);
+  {
+    const int nseg = (nb + 1 + kScanSeg - 1) / kScanSeg;
+    uint32_t *segsum = reinterpret_cast<uint32_t *>(ws + L.off_segsum);
+    hipLaunchKernelGGL(bucket_segsum_kernel, dim3(nseg, n), dim3(256), 0, stream, bstart, nb, nseg, segsum);
+    hipLaunchKernelGGL(bucket_segscan_kernel, dim3(n), dim3(1024), 0, stream, segsum, nseg);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, n), dim3(1024), 0, stream, bstart, cursor, nb, nseg,
+                       segsum);
+  }
   if (xrows > 0)
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, xrows, n,
                        hbmask, nb, cursor, order);
@@ -791,7 +869,7 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
                          d_ncand);
     flagged = ovf;
   }
-  const dim3 pgrid(flagged ? std::min<unsigned>(grid.x, 4096u) : grid.x);
+  const dim3 pgrid(flagged ? std::min<unsigned>(grid.x, 1024u) : grid.x);
 #define SPV_LAUNCH_PROBE(C, U)                                                                       \
   hipLaunchKernelGGL((probe_refine_kernel<C, U>), pgrid, block, 0, stream, ux, uy, xrows, yrows, dim, \
                      m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, flagged, d_idx, d_dist,    \
