@@ -176,3 +176,29 @@ def test_workspace_too_small_is_an_error():
     st = clib.spv_l1k2_device(x.data_ptr(), x.data_ptr(), 1000, 1000, 128, idx.data_ptr(), dist.data_ptr(),
                               ws.data_ptr(), 16, None)
     assert st == SPV_ERR_INVALID and b"workspace" in clib.spv_last_error()
+
+
+def test_extreme_aspect_ratios(oracle):
+    """One query against millions of rows (2048 slices, 64-lane merge) and a million queries
+    against a handful of rows."""
+    import torch
+    from spectavi_amd import device
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randint(0, 256, (3_000_001, 128), dtype=torch.uint8, device="cuda", generator=g)
+    y = torch.randint(0, 256, (3, 128), dtype=torch.uint8, device="cuda", generator=g)
+    x[2_999_999] = y[1]            # exact match in the very last slice
+    x[5] = y[1]                    # and an earlier duplicate: lower index must win
+    idx, dist = device.l1k2(x, y)
+    torch.cuda.synchronize()
+    oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y.cpu().numpy(), nthreads=oracle.max_threads())
+    assert np.array_equal(idx.cpu().numpy().view(np.uint64), oidx) and np.array_equal(dist.cpu().numpy(), odist)
+    assert idx[1].tolist() == [5, 2_999_999] and dist[1].tolist() == [0, 0]
+    xs = torch.randint(0, 256, (3, 128), dtype=torch.uint8, device="cuda", generator=g)
+    ys = torch.randint(0, 256, (1_000_003, 128), dtype=torch.uint8, device="cuda", generator=g)
+    idx, dist = device.l1k2(xs, ys)
+    torch.cuda.synchronize()
+    sub = np.arange(0, 1_000_003, 977)
+    oidx, odist = oracle.nn_bruteforcel1k2(xs.cpu().numpy(), ys[sub].cpu().numpy(), nthreads=8)
+    assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist[sub].cpu().numpy(), odist)
+    assert bool((idx >= 0).all()) and bool((idx < 3).all())
