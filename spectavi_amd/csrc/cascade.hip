@@ -25,9 +25,9 @@
 //                     one 128-byte candidate row (8 different queries' lines per wave
 //                     instruction), v_sad_u8 + DPP reduce, branch-free two smallest
 //                     (dist, idx) keys
-//   7 probe_refine    one wave per query, any candidate count / full-code check
-//                     (m > 22): redoes the queries kernel 6 flagged as overflowing, or
-//                     everything when kernel 6 does not apply
+//   7 probe_refine    one wave per query (the first design, issue-bound): used when
+//                     kernel 6 does not apply -- full-code check (m > 22) or rows wider
+//                     than 256 bytes
 //
 // Candidate semantics (closed form of filter_potential_neighbours, :208-227):
 // database row k is a candidate of query i iff for some table j
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
     uint32_t *__restrict__ masks,        // [n][nrows] (queries only)
     uint8_t *__restrict__ u8img,         // [nrows][dim]
     uint32_t *__restrict__ counts,       // [n][nb+1] bucket histogram (database only, may be NULL)
+    uint32_t *__restrict__ ranks,        // [n][nrows] rank of the row inside its bucket (database only)
     uint32_t hbmask, int nb) {
   constexpr int R = kProjRows;
   __shared__ __attribute__((aligned(16))) uint8_t xs[kProjTile * kProjXStride];  // row tile, 16 dims
@@ -218,7 +219,10 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
         if (r < nrows) {
           codes[(size_t)j * nrows + r] = code;
           // database rows: bucket histogram for the counting sort, fused here
-          if (!IS_QUERY && counts) atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
+          // (the value the atomic returns is the row's rank inside its bucket: the fill pass
+          // needs no second round of atomics)
+          if (!IS_QUERY && counts)
+            ranks[(size_t)j * nrows + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
         }
         if (IS_QUERY) {
           // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
@@ -337,15 +341,16 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict_
   }
 }
 
-__global__ void bucket_fill_kernel(const uint32_t *__restrict__ codes, int M, int n,
-                                   uint32_t hbmask, int nb, uint32_t *__restrict__ cursor,
+__global__ void bucket_fill_kernel(const uint32_t *__restrict__ codes,
+                                   const uint32_t *__restrict__ ranks, int M, int n, uint32_t hbmask,
+                                   int nb, const uint32_t *__restrict__ bstart,
                                    uint32_t *__restrict__ order) {
   const size_t total = (size_t)n * M;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(e / M);
     const uint32_t idx = (uint32_t)(e - (size_t)j * M);
-    const uint32_t pos = atomicAdd(&cursor[(size_t)j * (nb + 1) + (codes[e] & hbmask)], 1u);
+    const uint32_t pos = bstart[(size_t)j * (nb + 1) + (codes[e] & hbmask)] + ranks[e];
     order[(size_t)j * M + pos] = idx;
   }
 }
@@ -592,10 +597,10 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
 // gathers ONE candidate row (8 lanes x 16 bytes = one 128-byte line, 8 different
 // queries' lines per wave instruction), v_sad_u8 + DPP sum, branch-free top-2.  All 8
 // lanes of a group hold the same keys, so no cross-lane merge is needed at the end.
-// A query whose pass needs more than kGroupCap list entries is flagged and redone by the
-// wave-per-query kernel (second launch, flagged queries only).
+// A pass whose candidate stream is longer than kGroupCap entries is processed in several
+// windows of the list.
 // ---------------------------------------------------------------------------------
-constexpr int kGroupCap = 288;  // candidate indices per group per pass (32 groups -> 36 KB LDS)
+constexpr int kGroupCap = 256;  // candidate indices per group per window (32 groups -> 32 KB LDS)
 
 __device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
@@ -605,8 +610,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
     const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int n,
     int g, int hb, const uint32_t *__restrict__ ysign, const uint32_t *__restrict__ ymask,
     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ order,
-    uint8_t *__restrict__ overflow, uint64_t *__restrict__ out_idx, float *__restrict__ out_dist,
-    int32_t *__restrict__ out_ncand) {
+    uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
   __shared__ uint32_t lists[kThreads / 8][kGroupCap];
   const int t = threadIdx.x;
   const int sub = t & 7;
@@ -629,7 +633,6 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
   }
   uint64_t k1 = kNone64, k2 = kNone64;
   int visited = 0;
-  bool ovf = false;
 
   for (int p0 = 0; p0 < nprobe; p0 += 8) {
     // lane `sub` owns probe p0 + sub of this pass
@@ -655,62 +658,70 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
     }
     const uint32_t total = __shfl(incl, 7, 8);
     const uint32_t excl = incl - len;
-    if (total > (uint32_t)kGroupCap) ovf = true;
-    const uint32_t T = ovf ? 0u : total;
-    // copy the buckets: bucket b is broadcast from lane b, all 8 lanes copy it
-    for (int b = 0; b < 8; ++b) {
-      const uint32_t bl = ovf ? 0u : __shfl(len, b, 8);
-      const uint32_t bs_ = __shfl(s, b, 8);
-      const uint32_t bo = __shfl(excl, b, 8);
-      const int bj = __shfl(tj, b, 8);
-      const uint32_t *src = order + (size_t)bj * M + bs_;
-      for (uint32_t e = sub; e < bl; e += 8) list[bo + e] = src[e];
-    }
-    __builtin_amdgcn_wave_barrier();
-    visited += (int)T;
-    // rounds: one candidate row per group per round, RU rounds in flight
-    for (uint32_t f0 = 0; __any(f0 < T); f0 += RU) {
-      uint4 xv[RU][CPL];
-      uint32_t cand[RU];
-      bool live[RU];
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        live[u] = f0 + u < T;
-        cand[u] = list[live[u] ? f0 + u : 0];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          const int ch = sub + 8 * c;
-          xv[u][c] = make_uint4(0, 0, 0, 0);
-          if (live[u] && ch < nchunk)
-            xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)cand[u] * dim + 16 * ch);
+    visited += (int)total;
+    // the pass's candidate stream [0, total) is processed in windows of kGroupCap entries
+    // (one window almost always; skewed buckets simply take more)
+    for (uint32_t w0 = 0; __any(w0 < total); w0 += kGroupCap) {
+      const uint32_t T = w0 < total ? min((uint32_t)kGroupCap, total - w0) : 0u;
+      // copy the window's part of every bucket: bucket b is broadcast from lane b, all 8
+      // lanes copy it
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t bl = __shfl(len, b, 8);
+        const uint32_t bs_ = __shfl(s, b, 8);
+        const uint32_t bo = __shfl(excl, b, 8);
+        const int bj = __shfl(tj, b, 8);
+        const uint32_t *src = order + (size_t)bj * M + bs_;
+        // entries e of the bucket sit at stream positions bo + e; keep those inside the window
+        const uint32_t e_lo = w0 > bo ? w0 - bo : 0u;
+        const uint32_t e_hi = bo + bl > w0 + T ? (w0 + T > bo ? w0 + T - bo : 0u) : bl;
+        for (uint32_t e = (e_lo & ~7u) + sub; e < e_hi; e += 8)
+          if (e >= e_lo) list[bo + e - w0] = src[e];
+      }
+      __builtin_amdgcn_wave_barrier();
+      // rounds: one candidate row per group per round, RU rounds in flight
+      for (uint32_t f0 = 0; __any(f0 < T); f0 += RU) {
+        uint4 xv[RU][CPL];
+        uint32_t cand[RU];
+        bool live[RU];
+  #pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          live[u] = f0 + u < T;
+          cand[u] = list[live[u] ? f0 + u : 0];
+  #pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int ch = sub + 8 * c;
+            xv[u][c] = make_uint4(0, 0, 0, 0);
+            if (live[u] && ch < nchunk)
+              xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)cand[u] * dim + 16 * ch);
+          }
+        }
+  #pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          uint32_t d = 0;
+  #pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            d = sad_u8(qv[c].x, xv[u][c].x, d);
+            d = sad_u8(qv[c].y, xv[u][c].y, d);
+            d = sad_u8(qv[c].z, xv[u][c].z, d);
+            d = sad_u8(qv[c].w, xv[u][c].w, d);
+          }
+          d = group8_sum(d);
+          // branch-free insertion of a key that may repeat (same row reached via another table)
+          uint64_t k = ((uint64_t)d << 32) | cand[u];
+          const bool skip = !live[u] || k == k1 || k == k2;
+          k = skip ? kNone64 : k;
+          const uint64_t hi = max_u64(k, k1);
+          k1 = min_u64(k, k1);
+          k2 = min_u64(hi, k2);
         }
       }
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        uint32_t d = 0;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          d = sad_u8(qv[c].x, xv[u][c].x, d);
-          d = sad_u8(qv[c].y, xv[u][c].y, d);
-          d = sad_u8(qv[c].z, xv[u][c].z, d);
-          d = sad_u8(qv[c].w, xv[u][c].w, d);
-        }
-        d = group8_sum(d);
-        // branch-free insertion of a key that may repeat (same row reached via another table)
-        uint64_t k = ((uint64_t)d << 32) | cand[u];
-        const bool skip = !live[u] || k == k1 || k == k2;
-        k = skip ? kNone64 : k;
-        const uint64_t hi = max_u64(k, k1);
-        k1 = min_u64(k, k1);
-        k2 = min_u64(hi, k2);
-      }
+      __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_wave_barrier();
   }
 
   if (valid && sub == 0) {
-    overflow[query] = ovf ? 1 : 0;
-    if (!ovf) {
+    {
       const bool n1 = k1 == kNone64, n2 = k2 == kNone64;
       out_idx[2 * (size_t)query + 0] = n1 ? ~0ull : (k1 & 0xFFFFFFFFull);
       out_idx[2 * (size_t)query + 1] = n2 ? ~0ull : (k2 & 0xFFFFFFFFull);
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
 struct CascadeLayout {
   int mc, hb;
   size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart, off_cursor,
-      off_order, off_ovf, off_segsum, total;
+      off_order, off_ranks, off_segsum, total;
 };
 
 CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
@@ -747,7 +758,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   L.off_bstart = take((size_t)n * nb1 * sizeof(uint32_t));
   L.off_cursor = take((size_t)n * nb1 * sizeof(uint32_t));
   L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
-  L.off_ovf = take((size_t)yrows);
+  L.off_ranks = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_segsum = take((size_t)n * ((nb1 + kScanSeg - 1) / kScanSeg) * sizeof(uint32_t));
   L.total = off;
   return L;
@@ -756,7 +767,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
 template <bool IS_QUERY>
 void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m, int n,
                     const float *dictp, uint32_t *codes, uint32_t *masks, uint8_t *img,
-                    uint32_t *counts, uint32_t hbmask, int nb, hipStream_t stream) {
+                    uint32_t *counts, uint32_t *ranks, uint32_t hbmask, int nb, hipStream_t stream) {
   if (nrows <= 0) return;
   const dim3 grid((nrows + kProjTile - 1) / kProjTile), block(kThreads);
   constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
@@ -764,10 +775,10 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
 #define SPV_LAUNCH_PROJECT(MCV, NTV)                                                           \
   if (g <= G1)                                                                                  \
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G1>), grid, block, 0, stream, rows,  \
-                       nrows, dim, m, n, g, dictp, codes, masks, img, counts, hbmask, nb);      \
+                       nrows, dim, m, n, g, dictp, codes, masks, img, counts, ranks, hbmask, nb); \
   else                                                                                          \
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G2>), grid, block, 0, stream, rows,  \
-                       nrows, dim, m, n, g, dictp, codes, masks, img, counts, hbmask, nb);
+                       nrows, dim, m, n, g, dictp, codes, masks, img, counts, ranks, hbmask, nb);
   const bool two = n >= 2;
   switch (mc) {
     case 8:
@@ -811,7 +822,7 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   uint32_t *bstart = reinterpret_cast<uint32_t *>(ws + L.off_bstart);
   uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.off_cursor);
   uint32_t *order = reinterpret_cast<uint32_t *>(ws + L.off_order);
-  uint8_t *ovf = ws + L.off_ovf;
+  uint32_t *ranks = reinterpret_cast<uint32_t *>(ws + L.off_ranks);
   const int nb = 1 << L.hb;
   const uint32_t hbmask = (uint32_t)nb - 1;
 
@@ -820,10 +831,10 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   ProfScope prof("cascade_project", stream);
   hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
                      m, L.mc);
-  launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, bstart, hbmask, nb,
-                        stream);
-  launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, nullptr, hbmask, nb,
-                       stream);
+  launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, bstart, ranks, hbmask,
+                        nb, stream);
+  launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, nullptr, nullptr, hbmask,
+                       nb, stream);
   }
   SPV_HIP_CHECK(hipGetLastError());
 
@@ -838,8 +849,8 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
                        segsum);
   }
   if (xrows > 0)
-    hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, xrows, n,
-                       hbmask, nb, cursor, order);
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, ranks, xrows, n,
+                       hbmask, nb, bstart, order);
   }
   SPV_HIP_CHECK(hipGetLastError());
 
@@ -849,27 +860,26 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     return set_error(SPV_ERR_INVALID, "dim=%d > 512 is not supported by the cascade refine kernel",
                      dim);
   ProfScope prof_probe("cascade_probe_refine", stream);
-  // group-per-query kernel first (unless the full-code check is needed: m > bucket bits);
-  // the wave-per-query kernel then redoes only the queries it flagged as overflowing
+  // group-per-query kernel unless the full-code check is needed (m > bucket bits) or rows
+  // are wider than 256 bytes; otherwise the wave-per-query kernel
   static const bool group_env = [] {
     const char *e = getenv("SPECTAVI_CASCADE_GROUP");
     return !(e && e[0] == '0');
   }();
   const bool use_group = group_env && m <= L.hb && cpl <= 2;
-  const uint8_t *flagged = nullptr;
   if (use_group) {
     const dim3 ggrid((yrows + kThreads / 8 - 1) / (kThreads / 8));
     if (cpl == 1)
       hipLaunchKernelGGL((probe_refine_group_kernel<1, 4>), ggrid, block, 0, stream, ux, uy, xrows,
-                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, ovf, d_idx, d_dist,
-                         d_ncand);
+                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand);
     else
       hipLaunchKernelGGL((probe_refine_group_kernel<2, 2>), ggrid, block, 0, stream, ux, uy, xrows,
-                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, ovf, d_idx, d_dist,
-                         d_ncand);
-    flagged = ovf;
+                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand);
+    SPV_HIP_CHECK(hipGetLastError());
+    return SPV_OK;
   }
-  const dim3 pgrid(flagged ? std::min<unsigned>(grid.x, 1024u) : grid.x);
+  const dim3 pgrid(grid.x);
+  const uint8_t *flagged = nullptr;  // the kernel can restrict itself to flagged queries; unused now
 #define SPV_LAUNCH_PROBE(C, U)                                                                       \
   hipLaunchKernelGGL((probe_refine_kernel<C, U>), pgrid, block, 0, stream, ux, uy, xrows, yrows, dim, \
                      m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, flagged, d_idx, d_dist,    \
