@@ -265,8 +265,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
 // ---------------------------------------------------------------------------------
 // Exclusive scan of counts[j][0..nb] in place, three small kernels: per-segment sums
 // (1024 entries each), a scan of the segment sums (one workgroup per table), and the
-// segment-local scans with the carried offset.  cursor[j][b] receives a copy of the start
-// offsets for the fill pass.
+// segment-local scans with the carried offset.
 constexpr int kScanSeg = 1024;
 
 __global__ __launch_bounds__(256) void bucket_segsum_kernel(const uint32_t *__restrict__ counts,
@@ -313,14 +312,12 @@ __global__ __launch_bounds__(1024) void bucket_segscan_kernel(uint32_t *__restri
   }
 }
 
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict__ counts,
-                                                           uint32_t *__restrict__ cursor, int nb,
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict__ counts, int nb,
                                                            int nseg,
                                                            const uint32_t *__restrict__ segoff) {
   __shared__ uint32_t wsum[16];
   const int j = blockIdx.y, seg = blockIdx.x;
   uint32_t *c = counts + (size_t)j * (nb + 1);
-  uint32_t *cu = cursor + (size_t)j * (nb + 1);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int e = seg * kScanSeg + t;
   const uint32_t v = e <= nb ? c[e] : 0u;
@@ -335,10 +332,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict_
   uint32_t woff = segoff[(size_t)j * nseg + seg];
   for (int k = 0; k < w; ++k) woff += wsum[k];
   const uint32_t excl = woff + incl - v;
-  if (e <= nb) {
-    c[e] = excl;
-    cu[e] = excl;
-  }
+  if (e <= nb) c[e] = excl;
 }
 
 __global__ void bucket_fill_kernel(const uint32_t *__restrict__ codes,
@@ -734,7 +728,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
 
 struct CascadeLayout {
   int mc, hb;
-  size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart, off_cursor,
+  size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart,
       off_order, off_ranks, off_segsum, total;
 };
 
@@ -756,7 +750,6 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   L.off_ysign = take((size_t)n * yrows * sizeof(uint32_t));
   L.off_ymask = take((size_t)n * yrows * sizeof(uint32_t));
   L.off_bstart = take((size_t)n * nb1 * sizeof(uint32_t));
-  L.off_cursor = take((size_t)n * nb1 * sizeof(uint32_t));
   L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_ranks = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_segsum = take((size_t)n * ((nb1 + kScanSeg - 1) / kScanSeg) * sizeof(uint32_t));
@@ -820,7 +813,6 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   uint32_t *ysign = reinterpret_cast<uint32_t *>(ws + L.off_ysign);
   uint32_t *ymask = reinterpret_cast<uint32_t *>(ws + L.off_ymask);
   uint32_t *bstart = reinterpret_cast<uint32_t *>(ws + L.off_bstart);
-  uint32_t *cursor = reinterpret_cast<uint32_t *>(ws + L.off_cursor);
   uint32_t *order = reinterpret_cast<uint32_t *>(ws + L.off_order);
   uint32_t *ranks = reinterpret_cast<uint32_t *>(ws + L.off_ranks);
   const int nb = 1 << L.hb;
@@ -845,8 +837,7 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     uint32_t *segsum = reinterpret_cast<uint32_t *>(ws + L.off_segsum);
     hipLaunchKernelGGL(bucket_segsum_kernel, dim3(nseg, n), dim3(256), 0, stream, bstart, nb, nseg, segsum);
     hipLaunchKernelGGL(bucket_segscan_kernel, dim3(n), dim3(1024), 0, stream, segsum, nseg);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, n), dim3(1024), 0, stream, bstart, cursor, nb, nseg,
-                       segsum);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, n), dim3(1024), 0, stream, bstart, nb, nseg, segsum);
   }
   if (xrows > 0)
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, ranks, xrows, n,

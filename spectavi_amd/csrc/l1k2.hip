@@ -96,6 +96,37 @@ __device__ __forceinline__ void row_update(const uint32_t (&qreg)[Q][D4], const 
   }
 }
 
+// Half-row form for wide descriptors (dim 192 / 256): the row is consumed as two chunks of
+// H4 = D4/2 dwords so that only one chunk-sized buffer pair is live next to 2 x D4 query
+// registers (two queries per lane keep the LDS broadcast amortised).
+template <int D4, int Q, int HALF>
+__device__ __forceinline__ void half_accumulate(const uint32_t (&qreg)[Q][D4],
+                                                const uint4 (&xh)[D4 / 8], uint32_t (&acc)[Q]) {
+  constexpr int H4 = D4 / 2;
+#pragma unroll
+  for (int c = 0; c < H4 / 4; ++c) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 0], xh[c].x, acc[q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 1], xh[c].y, acc[q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 2], xh[c].z, acc[q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 3], xh[c].w, acc[q]);
+  }
+}
+
+template <int Q>
+__device__ __forceinline__ void lazy_top2(const uint32_t (&acc)[Q], uint32_t (&k1)[Q], uint32_t (&k2)[Q]) {
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) any |= acc[q] < k2[q];
+  if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) top2_insert(k1[q], k2[q], acc[q]);
+  }
+}
+
 // Partial-key layout: part[(query * S + slice) * 2 + {0,1}], key = dist<<32 | global idx.
 __device__ __forceinline__ uint64_t widen_key(uint32_t k, uint32_t slice_base) {
   if (k == kKeyNone) return kKey64None;
@@ -177,15 +208,33 @@ __global__ __launch_bounds__(kThreads, 2) void l1k2_tile_kernel(
     const uint4 *buf = tile[tl & 1];
     const uint32_t jbase = (uint32_t)(row0 - row_begin);
 
-    // two rows per iteration, next row's LDS reads issued before the current
-    // row's SAD chain so the broadcast reads hide behind VALU work
-    uint4 xa[V4], xb[V4];
-    lds_row<V4>(xa, buf);
-    for (int r = 0; r < nrows; r += 2) {
-      lds_row<V4>(xb, buf + min(r + 1, kTileRows - 1) * V4);
-      row_update<D4, Q>(qreg, xa, jbase + r, k1, k2);
-      lds_row<V4>(xa, buf + min(r + 2, kTileRows - 1) * V4);
-      if (r + 1 < nrows) row_update<D4, Q>(qreg, xb, jbase + r + 1, k1, k2);
+    if constexpr (D4 >= 48) {
+      // wide rows: two half-row chunks per row, the next chunk's LDS reads issued before
+      // the current chunk's SAD chain
+      constexpr int HV = V4 / 2;
+      uint4 xa[HV], xb[HV];
+      lds_row<HV>(xa, buf);
+      for (int r = 0; r < nrows; ++r) {
+        uint32_t acc[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = jbase + r;
+        lds_row<HV>(xb, buf + r * V4 + HV);
+        half_accumulate<D4, Q, 0>(qreg, xa, acc);
+        lds_row<HV>(xa, buf + min(r + 1, kTileRows - 1) * V4);
+        half_accumulate<D4, Q, 1>(qreg, xb, acc);
+        lazy_top2<Q>(acc, k1, k2);
+      }
+    } else {
+      // two rows per iteration, next row's LDS reads issued before the current
+      // row's SAD chain so the broadcast reads hide behind VALU work
+      uint4 xa[V4], xb[V4];
+      lds_row<V4>(xa, buf);
+      for (int r = 0; r < nrows; r += 2) {
+        lds_row<V4>(xb, buf + min(r + 1, kTileRows - 1) * V4);
+        row_update<D4, Q>(qreg, xa, jbase + r, k1, k2);
+        lds_row<V4>(xa, buf + min(r + 2, kTileRows - 1) * V4);
+        if (r + 1 < nrows) row_update<D4, Q>(qreg, xb, jbase + r + 1, k1, k2);
+      }
     }
 
     if (has_next) stage_store(tile[(tl + 1) & 1]);
@@ -422,7 +471,7 @@ void launch_tile(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Pla
 template <int D4>
 void launch_tile_q(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Plan &p,
                    uint64_t *part, hipStream_t stream) {
-  constexpr int QMAX = D4 <= 16 ? 4 : (D4 <= 36 ? 2 : 1);
+  constexpr int QMAX = D4 <= 16 ? 4 : 2;
   if (p.q >= 4 && QMAX >= 4)
     launch_tile<D4, (QMAX >= 4 ? 4 : 1)>(x, y, M, N, p, part, stream);
   else if (p.q >= 2 && QMAX >= 2)
@@ -433,7 +482,9 @@ void launch_tile_q(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2P
 
 // Queries per lane.  Measured on MI355X at 256k x 256k, D=128 (tools/l1k2_sweep.py): Q=2
 // (154 VGPRs, 3 waves/SIMD) beats Q=4 (224 VGPRs, 2 waves/SIMD) by ~3 % and Q=1 by ~15 %.
-int max_q_for(int dim_pad) { return dim_pad <= 64 ? 4 : (dim_pad <= 144 ? 2 : 1); }
+// Wide rows (192 / 256) also take Q=2: with one query per lane the broadcast LDS reads, not
+// the SADs, bound the kernel (0.66 of the SAD peak measured at Q=1).
+int max_q_for(int dim_pad) { return dim_pad <= 64 ? 4 : 2; }
 
 }  // namespace
 

@@ -119,6 +119,38 @@ def end_to_end():
                       "data": "synthetic"}), flush=True)
 
 
+def l1k2_shapes(steps, warmup):
+    """Other descriptor widths and small problems (device-resident, kernel + merge)."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11)
+    for rows, dim in ((262144, 64), (262144, 144), (262144, 192), (262144, 256), (65536, 512),
+                      (1000, 128), (10000, 128)):
+        x = torch.randint(0, 256, (rows, dim), dtype=torch.uint8, device=dev, generator=g)
+        y = torch.randint(0, 256, (rows, dim), dtype=torch.uint8, device=dev, generator=g)
+        _, dt = timed(lambda: spv.l1k2(x, y), steps, warmup)
+        n, ms = spv.profile_read("l1k2_tile")
+        ks = ms / max(n, 1) / 1e3
+        ops = float(rows) * rows * (dim // 4)
+        print(json.dumps({"metric": "L1 2-NN, pairs/s", "value": float(rows) * rows / dt, "unit": "pairs/s",
+                          "ms_per_step": dt * 1e3, "kernel_ms": ks * 1e3,
+                          "sad_lane_ops_per_s": ops / ks, "frac_of_sad_peak": ops / ks / 39.3216e12,
+                          "config": {"workload": "%d x %d, D=%d" % (rows, rows, dim)}, "dtype": "u8",
+                          "data": "synthetic"}), flush=True)
+    # host-pointer latency of small calls (numpy in/out through nn_bruteforcel1k2)
+    rng = np.random.default_rng(2)
+    for rows in (1000, 10000):
+        xh = rng.integers(0, 256, (rows, 128), dtype=np.uint8)
+        yh = rng.integers(0, 256, (rows, 128), dtype=np.uint8)
+        feature.nn_bruteforcel1k2(xh, yh)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            feature.nn_bruteforcel1k2(xh, yh)
+        dt = (time.perf_counter() - t0) / 20
+        print(json.dumps({"metric": "nn_bruteforcel1k2 host-pointer call latency", "value": dt * 1e3, "unit": "ms",
+                          "ms_per_step": dt * 1e3, "config": {"workload": "%d x %d, D=128, numpy in/out" % (rows, rows)},
+                          "dtype": "u8", "data": "synthetic"}), flush=True)
+
+
 def next_rows(steps, warmup):
     """The SURVEY 8(f) rows: RANSAC scoring, ratio test, normalisation, SIFT adapter."""
     dev = torch.device("cuda")
@@ -195,4 +227,5 @@ if __name__ == "__main__":
     cascade(a.rows, a.steps, a.warmup, planted=True)
     dlt(a.npt, a.steps, a.warmup)
     next_rows(a.steps, a.warmup)
+    l1k2_shapes(a.steps, a.warmup)
     end_to_end()
