@@ -262,7 +262,7 @@ int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yr
   SPV_TRY(di.alloc((size_t)yrows * 2 * sizeof(uint64_t)));
   SPV_TRY(dd.alloc((size_t)yrows * 2 * sizeof(int32_t)));
   SPV_TRY(ws.alloc(wsb));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   if (xb) SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, xb, hipMemcpyHostToDevice, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dy.p, y, yb, hipMemcpyHostToDevice, st));
   SPV_TRY(l1k2_run(dx.as<uint8_t>(), dy.as<uint8_t>(), xrows, yrows, dim, di.as<uint64_t>(),
@@ -314,7 +314,7 @@ int host_cascade_one(int dev, const float *x, const float *y, int xrows, int yro
   SPV_TRY(dds.alloc((size_t)yrows * 2 * sizeof(float)));
   SPV_TRY(dn.alloc((size_t)yrows * sizeof(int32_t)));
   SPV_TRY(ws.alloc(wsb));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   if (xb) SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, xb, hipMemcpyHostToDevice, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dy.p, y, yb, hipMemcpyHostToDevice, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dd.p, dict, db, hipMemcpyHostToDevice, st));
@@ -353,7 +353,7 @@ int host_dlt_one(int dev, const double *P0, const double *P1, int npt, const dou
   SPV_TRY(dx.alloc(ib));
   SPV_TRY(dxp.alloc(ib));
   SPV_TRY(dd.alloc(ob));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, xp, ib, hipMemcpyHostToDevice, st));
   SPV_TRY(dlt_run(P0, P1, npt, dx.as<double>(), dxp.as<double>(), dd.as<double>(), want_error, st));
@@ -385,7 +385,7 @@ int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const
   SPV_TRY(dp.alloc((size_t)nhyp * 12 * sizeof(double)));
   SPV_TRY(dc.alloc((size_t)nhyp * sizeof(int32_t)));
   if (mask) SPV_TRY(dm.alloc((size_t)nhyp * npt));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   if (ib) {
     SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
     SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, xp, ib, hipMemcpyHostToDevice, st));
@@ -415,7 +415,7 @@ int host_ratio(const uint64_t *idx, const void *dist, int dist_is_float, int yro
   SPV_TRY(dm.alloc((size_t)yrows * 2 * sizeof(int32_t)));
   SPV_TRY(dc.alloc(sizeof(int32_t)));
   SPV_TRY(ws.alloc(wsb));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   SPV_HIP_CHECK(hipMemcpyAsync(di.p, idx, (size_t)yrows * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dd.p, dist, (size_t)yrows * 2 * 4, hipMemcpyHostToDevice, st));
   SPV_TRY(ratio_run(di.as<uint64_t>(), dd.p, dist_is_float, yrows, min_ratio, dm.as<int>(), dc.as<int>(),
@@ -436,7 +436,7 @@ int host_sift_split(const float *table, int rows, float *geom, uint8_t *desc) {
   SPV_TRY(dt.alloc((size_t)rows * 132 * sizeof(float)));
   SPV_TRY(dg.alloc((size_t)rows * 4 * sizeof(float)));
   SPV_TRY(dd.alloc((size_t)rows * 128));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   SPV_HIP_CHECK(hipMemcpyAsync(dt.p, table, (size_t)rows * 132 * sizeof(float), hipMemcpyHostToDevice, st));
   SPV_TRY(sift_split_run(dt.as<float>(), rows, dg.as<float>(), dd.as<uint8_t>(), st));
   SPV_HIP_CHECK(hipMemcpyAsync(geom, dg.p, (size_t)rows * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -456,7 +456,7 @@ int host_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *o
   if (out_f32) SPV_TRY(df.alloc((size_t)rows * dim16 * sizeof(float)));
   if (out_u8) SPV_TRY(du.alloc((size_t)rows * dim16));
   SPV_TRY(ws.alloc(normalize_workspace_bytes(dim)));
-  hipStream_t st = nullptr;
+  hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, (size_t)rows * dim * sizeof(float), hipMemcpyHostToDevice, st));
   SPV_TRY(normalize_run(dx.as<float>(), rows, dim, out_f32 ? df.as<float>() : nullptr,
                         out_u8 ? du.as<unsigned char>() : nullptr, ws.p, normalize_workspace_bytes(dim), st));

@@ -49,3 +49,38 @@ def test_bad_device_is_reported():
             feature.nn_bruteforcel1k2(np.zeros((8, 16), np.uint8), np.zeros((8, 16), np.uint8))
     finally:
         spectavi_amd.set_devices([0])
+
+
+def test_concurrent_callers(oracle):
+    """ctypes releases the GIL: four Python threads inside libspectavi at once (per-thread
+    streams, shared device-buffer cache) must each get their own correct result."""
+    import threading
+    from spectavi_amd import feature, mvg
+    rng = np.random.default_rng(31)
+    jobs = []
+    for k in range(4):
+        x = rng.integers(0, 256, (2000 + 300 * k, 128), dtype=np.uint8)
+        y = rng.integers(0, 256, (1500 + 200 * k, 128), dtype=np.uint8)
+        jobs.append((x, y, oracle.nn_bruteforcel1k2(x, y, nthreads=4)))
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((50000, 4))
+    want_X = oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(5):
+                x, y, (oi, od) = jobs[k]
+                i, d = feature.nn_bruteforcel1k2(x, y)
+                assert np.array_equal(i, oi) and np.array_equal(d, od)
+                X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+                assert np.max(np.abs(X - want_X)) <= 1e-12
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
