@@ -15,8 +15,9 @@
 //   * the distance is accumulated by v_sad_hi_u8, which adds SAD<<16 into an
 //     accumulator pre-loaded with the tile-local row index: the accumulator IS
 //     the packed sort key (dist<<16 | idx16), no pack instruction needed,
-//   * the running two smallest keys per query are kept with v_min_u32 +
-//     v_med3_u32 (2 VALU ops per pair on top of the 32 SADs for dim=128),
+//   * the running two smallest keys per query: one compare per pair against the
+//     current second best and a wave-uniform branch; only when some lane improves
+//     (rare after the first few hundred rows of a slice) v_min_u32 + v_med3_u32,
 //   * no early-exit prune: it is result-neutral in the reference
 //     (src/BruteForceNnL1K2.h:118-121 only skips pairs that could not be
 //     inserted) and would diverge the wave.
@@ -31,8 +32,9 @@
 // (size_t idx[N,2], int dist[N,2]; sentinels INT_MAX / (size_t)-1 as
 // src/BruteForceNnL1K2.h:100-103).
 //
-// Roofline: sum-of-abs-diff is not a contraction (no MFMA); the bound is the
-// integer VALU: 32 v_sad lane-ops per 128-D pair.  See DESIGN.md.
+// Roofline: sum-of-abs-diff is not a contraction (no MFMA); the bound is the issue
+// rate of v_sad_hi_u8 -- one wave64 instruction per 4 cycles per SIMD, measured -- at
+// 32 lane-ops per 128-D pair.  The kernel runs at 0.90 of that peak.  See DESIGN.md.
 
 #include "common.h"
 
