@@ -64,7 +64,8 @@ def test_concurrent_callers(oracle):
         jobs.append((x, y, oracle.nn_bruteforcel1k2(x, y, nthreads=4)))
     P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
     Xw = rng.standard_normal((50000, 4))
-    want_X = oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    xa, xb = Xw @ P0.T, Xw @ P1.T  # once: a threaded BLAS need not reproduce its own bits
+    want_X = oracle.dlt_triangulate(P0, P1, xa, xb)
     errors = []
 
     def work(k):
@@ -73,7 +74,7 @@ def test_concurrent_callers(oracle):
                 x, y, (oi, od) = jobs[k]
                 i, d = feature.nn_bruteforcel1k2(x, y)
                 assert np.array_equal(i, oi) and np.array_equal(d, od)
-                X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+                X = mvg.dlt_triangulate(P0, P1, xa, xb)
                 assert np.max(np.abs(X - want_X)) <= 1e-12
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
