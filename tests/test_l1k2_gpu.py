@@ -202,3 +202,23 @@ def test_extreme_aspect_ratios(oracle):
     assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
     assert np.array_equal(dist[sub].cpu().numpy(), odist)
     assert bool((idx >= 0).all()) and bool((idx < 3).all())
+
+
+def test_config5_database_size(oracle):
+    """BASELINE configs[4] shards 4M queries over 8 GPUs against a replicated 4M-row database.
+    One GPU's database size (4M x 128) with a 2048-query sample of its shard, bit-exact vs the
+    oracle, plus planted exact copies spread over all 64 database slices."""
+    import torch
+    from spectavi_amd import device
+    m, n = 4_000_000, 2048
+    g = torch.Generator(device="cuda").manual_seed(2026)
+    x = torch.randint(0, 256, (m, 128), dtype=torch.uint8, device="cuda", generator=g)
+    y = torch.randint(0, 256, (n, 128), dtype=torch.uint8, device="cuda", generator=g)
+    src = (torch.arange(0, 64, device="cuda") * 62_497 + 11) % m
+    y[:64] = x[src]
+    idx, dist = device.l1k2(x, y)
+    torch.cuda.synchronize()
+    assert bool((dist[:64, 0] == 0).all()) and bool((idx[:64, 0] == src).all())
+    oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y.cpu().numpy(), nthreads=oracle.max_threads())
+    assert np.array_equal(idx.cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist.cpu().numpy(), odist)
