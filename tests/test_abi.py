@@ -107,3 +107,50 @@ def test_no_gpu_is_a_loud_error():
     x = np.zeros((4, 16), np.uint8)
     with pytest.raises(_lib.SpectaviError):
         feature.nn_bruteforcel1k2(x, x)
+
+
+def test_frontend_signatures_match_reference_source():
+    """Where the reference tree is mounted (the build container; not the GPU box), check that the
+    hot-path front-end functions keep the reference's parameter names and defaults and that the
+    ctypes argtypes lists have the same length and scalar/pointer pattern.  Source is parsed as
+    text (ast), nothing is imported or executed from the reference."""
+    import ast
+    import inspect
+    ref_dir = "/root/reference/spectavi"
+    if not os.path.isdir(ref_dir):
+        pytest.skip("reference tree not present")
+    from spectavi_amd import feature, mvg
+
+    def ref_functions(path):
+        tree = ast.parse(open(path).read())
+        out = {}
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef):
+                names = [a.arg for a in node.args.args]
+                defaults = [ast.literal_eval(d) for d in node.args.defaults]
+                out[node.name] = (names, defaults)
+        return tree, out
+
+    def ref_argtypes_len(tree, var):
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute):
+                t = node.targets[0]
+                if t.attr == "argtypes" and isinstance(t.value, ast.Name) and t.value.id == var:
+                    return len(node.value.elts)
+        return None
+
+    ftree, ffun = ref_functions(os.path.join(ref_dir, "feature.py"))
+    mtree, mfun = ref_functions(os.path.join(ref_dir, "mvg.py"))
+    for mod, funs, names in ((feature, ffun, ["nn_bruteforcel1k2", "nn_cascading_hash",
+                                              "normalize_to_ubyte_and_multiple_16_dim"]),
+                             (mvg, mfun, ["dlt_triangulate", "dlt_reprojection_error", "hnormalize"])):
+        for name in names:
+            sig = inspect.signature(getattr(mod, name))
+            ours = list(sig.parameters)
+            our_defaults = [p.default for p in sig.parameters.values() if p.default is not inspect._empty]
+            assert ours == funs[name][0], name
+            assert our_defaults == funs[name][1], name
+    assert len(feature._nn_bruteforcel1k2.argtypes) == ref_argtypes_len(ftree, "_nn_bruteforcel1k2") == 8
+    assert len(feature._nn_cascading_hash.argtypes) == ref_argtypes_len(ftree, "_nn_cascading_hash") == 11
+    assert len(mvg._dlt_triangulate.argtypes) == ref_argtypes_len(mtree, "_dlt_triangulate") == 6
+    assert len(mvg._dlt_reprojection_error.argtypes) == ref_argtypes_len(mtree, "_dlt_reprojection_error") == 6
