@@ -116,3 +116,28 @@ def test_score_hypotheses_matches_oracle(oracle):
     err = mvg.dlt_reprojection_error(P0, P1s[0], x, xp)[:, 0]
     front = oracle.dlt_cheirality(P0, P1s[0], x, xp)
     assert np.array_equal(mask[0], (err <= 1e-2) & front)
+
+
+def test_many_camera_pairs_bit_exact(oracle):
+    """30 random camera pairs (some nearly degenerate), noisy and noise-free points: the HIP kernel
+    and the oracle run the same explicit-FMA operation sequence, so they agree to the last bit."""
+    from spectavi_amd import mvg
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for k in range(30):
+        P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+        if k % 5 == 0:
+            P1 = P0 + 1e-6 * rng.standard_normal((3, 4))   # almost no baseline
+        if k % 7 == 0:
+            P0[:, 3] *= 1e4                                 # badly scaled translation
+        Xw = rng.standard_normal((2003, 4))
+        x = Xw @ P0.T + (k % 2) * rng.normal(0, 1e-3, (2003, 3))
+        xp = Xw @ P1.T + (k % 2) * rng.normal(0, 1e-3, (2003, 3))
+        X = mvg.dlt_triangulate(P0, P1, x, xp)
+        oX = oracle.dlt_triangulate(P0, P1, x, xp)
+        assert np.array_equal(np.isnan(X), np.isnan(oX))
+        worst = max(worst, float(np.nanmax(np.abs(X - oX))))
+        e = mvg.dlt_reprojection_error(P0, P1, x, xp)
+        oe = oracle.dlt_reprojection_error(P0, P1, x, xp)
+        assert np.array_equal(e, oe, equal_nan=True)
+    assert worst == 0.0
