@@ -7,7 +7,7 @@
 // the L1 brute force as a candidate filter.  Here everything is flat arrays in
 // HBM and these kernels:
 //
-//   1 repack_dict     dict[n][dim][m] -> dictp[n][dim][MC], MC = roundup(m,8), zero padded
+//   1 repack_dict     dict[n][dim][m] -> dictp[n][dim][MC], MC = roundup(m,4), zero padded
 //   2 project<false>  database rows: n*m random-hyperplane projections as a
 //                     dim-ordered fp32 FMA chain (the oracle runs the identical
 //                     chain, so sign bits match bit for bit), sign-packed codes
@@ -734,7 +734,7 @@ struct CascadeLayout {
 
 CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   CascadeLayout L{};
-  L.mc = (m + 7) / 8 * 8;
+  L.mc = (m + 3) / 4 * 4;  // accumulators per table: multiples of 4 (one ds_read_b128 each)
   L.hb = bucket_bits(m);
   const size_t nb1 = ((size_t)1 << L.hb) + 1;
   size_t off = 0;
@@ -772,19 +772,29 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
   else                                                                                          \
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G2>), grid, block, 0, stream, rows,  \
                        nrows, dim, m, n, g, dictp, codes, masks, img, counts, ranks, hbmask, nb);
+  // two tables per pass while 2 x 2 x MC accumulators fit the register budget (MC <= 24)
   const bool two = n >= 2;
+#define SPV_PROJECT_CASE(MCV)                                             \
+  case MCV:                                                               \
+    if (two && MCV <= 24) {                                               \
+      SPV_LAUNCH_PROJECT(MCV, (MCV <= 24 ? 2 : 1))                        \
+    } else {                                                              \
+      SPV_LAUNCH_PROJECT(MCV, 1)                                          \
+    }                                                                     \
+    break;
   switch (mc) {
-    case 8:
-      if (two) { SPV_LAUNCH_PROJECT(8, 2) } else { SPV_LAUNCH_PROJECT(8, 1) }
+    SPV_PROJECT_CASE(4)
+    SPV_PROJECT_CASE(8)
+    SPV_PROJECT_CASE(12)
+    SPV_PROJECT_CASE(16)
+    SPV_PROJECT_CASE(20)
+    SPV_PROJECT_CASE(24)
+    SPV_PROJECT_CASE(28)
+    default:
+      SPV_LAUNCH_PROJECT(32, 1)
       break;
-    case 16:
-      if (two) { SPV_LAUNCH_PROJECT(16, 2) } else { SPV_LAUNCH_PROJECT(16, 1) }
-      break;
-    case 24:
-      if (two) { SPV_LAUNCH_PROJECT(24, 2) } else { SPV_LAUNCH_PROJECT(24, 1) }
-      break;
-    default: SPV_LAUNCH_PROJECT(32, 1) break;
   }
+#undef SPV_PROJECT_CASE
 #undef SPV_LAUNCH_PROJECT
 }
 
