@@ -70,6 +70,10 @@ int spv_profile_read(const char *kernel, long long *launches, double *total_ms);
  * operands only (op: 0 v_sad_hi_u8, 1 v_sad_u8, 2 v_sad_u16, 3 v_xor+v_add,
  * 4 v_fma_f32, 5 v_dot4_u32_u8, 6 v_med3_u32) and the shader clock held. */
 int spv_microbench_valu(int op, int blocks, int iters, double *lane_ops_per_s, double *clock_ghz);
+/* Diagnostic: memory ceilings.  mode 0 = 16-byte-per-lane streaming copy of table_bytes
+ * (bytes read + written per second); mode 1 = random 128-byte row gathers, 8 lanes per row,
+ * from a table of table_bytes (bytes gathered per second). */
+int spv_microbench_memory(int mode, size_t table_bytes, double *bytes_per_s);
 
 /* ------------------------------------------------------------------------ */
 /* 1. Reference-compatible symbols (same names, argument order and meaning)  */

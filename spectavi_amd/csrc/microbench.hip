@@ -107,3 +107,83 @@ extern "C" int spv_microbench_valu(int op, int blocks, int iters, double *lane_o
   (void)hipFree(clk);
   return SPV_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// Memory ceilings used by DESIGN.md for the cascade kernels: (a) a plain 16-byte-per-lane
+// streaming copy, (b) random 128-byte row gathers, 8 lanes per row (the access shape of
+// probe_refine_group_kernel), from a table of `table_bytes`.
+// ---------------------------------------------------------------------------------
+namespace spv {
+namespace {
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ src,
+                                                          uint4 *__restrict__ dst, size_t n) {
+  for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+    dst[e] = src[e];
+}
+
+__global__ __launch_bounds__(256) void gather128_kernel(const uint4 *__restrict__ table, size_t rows,
+                                                        uint32_t *__restrict__ out, int rounds,
+                                                        uint32_t seed) {
+  const int sub = threadIdx.x & 7;
+  const size_t grp = (blockIdx.x * (size_t)256 + threadIdx.x) >> 3;
+  uint32_t state = seed ^ (uint32_t)(grp * 2654435761u);
+  uint32_t acc = 0;
+  for (int r = 0; r < rounds; r += 4) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      state = state * 1664525u + 1013904223u;  // same row for the 8 lanes of a group
+      const size_t row = ((size_t)state * rows) >> 32;
+      v[u] = table[row * 8 + sub];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+  }
+  out[blockIdx.x * (size_t)256 + threadIdx.x] = acc;
+}
+
+}  // namespace
+}  // namespace spv
+
+// mode 0: streaming copy of `table_bytes` (reports bytes read + written per second);
+// mode 1: random 128-byte row gathers from a table of `table_bytes` (bytes gathered per second).
+extern "C" int spv_microbench_memory(int mode, size_t table_bytes, double *bytes_per_s) {
+  using namespace spv;
+  clear_error();
+  if (!bytes_per_s || table_bytes < 4096 || mode < 0 || mode > 1) return set_error(SPV_ERR_INVALID, "bad args");
+  int s = ensure_device();
+  if (s != SPV_OK) return s;
+  table_bytes &= ~(size_t)127;
+  void *a = nullptr, *b = nullptr;
+  SPV_HIP_CHECK(hipMalloc(&a, table_bytes));
+  SPV_HIP_CHECK(hipMalloc(&b, mode == 0 ? table_bytes : (size_t)2048 * 256 * 8 * 4));
+  SPV_HIP_CHECK(hipMemset(a, 1, table_bytes));
+  hipEvent_t e0, e1;
+  SPV_HIP_CHECK(hipEventCreate(&e0));
+  SPV_HIP_CHECK(hipEventCreate(&e1));
+  const int rounds = 256, blocks = 2048 * 8;
+  double moved = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) SPV_HIP_CHECK(hipEventRecord(e0, nullptr));
+    if (mode == 0) {
+      hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(256), 0, nullptr, static_cast<const uint4 *>(a),
+                         static_cast<uint4 *>(b), table_bytes / 16);
+      moved = 2.0 * (double)table_bytes;
+    } else {
+      hipLaunchKernelGGL(gather128_kernel, dim3(blocks), dim3(256), 0, nullptr, static_cast<const uint4 *>(a),
+                         table_bytes / 128, static_cast<uint32_t *>(b), rounds, 12345u + pass);
+      moved = (double)blocks * 32.0 * rounds * 128.0;
+    }
+  }
+  SPV_HIP_CHECK(hipEventRecord(e1, nullptr));
+  SPV_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SPV_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *bytes_per_s = moved / (ms * 1e-3);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  return SPV_OK;
+}
