@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout has no built artefacts (they are git-ignored): build the HIP library
+    # (hipcc cross-compiles gfx950 without a GPU) and the CPU oracle before collection, exactly
+    # what __graft_entry__.build() does.
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "spectavi_amd", "libspectavi.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "spectavi_amd", "csrc"), "-j", "4", "-s"])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
 
 
 @pytest.fixture(scope="session")
