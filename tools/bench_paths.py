@@ -72,6 +72,14 @@ def cascade(rows, steps, warmup, planted):
     }
     if planted:
         rec["recall_planted_top1"] = float((idx[:, 0] == perm).float().mean())
+    # recall against the exact L1 2-NN on a 10k-query subsample; uniform random data
+    # has no cluster structure, so a low value there is a property of the input
+    sub = torch.arange(0, rows, max(1, rows // 10000), device=dev)[:10000]
+    ux = (x + 128).to(torch.uint8).contiguous()
+    uy = (y[sub] + 128).to(torch.uint8).contiguous()
+    eidx, _ = spv.l1k2(ux, uy)
+    rec["recall_vs_exact_top1_10k"] = float((idx[sub, 0] == eidx[:, 0]).float().mean())
+    rec["recall_vs_exact_top2_10k"] = float((idx[sub] == eidx).float().mean())
     print(json.dumps(rec), flush=True)
 
 
