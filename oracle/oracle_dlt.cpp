@@ -14,8 +14,10 @@
 //   reference src/Spectavi.cpp:38-68        the serial per-point loops
 //
 // The SVD itself lives in Eigen (JacobiSVD, version unpinned by the reference
-// build, absent here).  It is restated as a one-sided (Hestenes) Jacobi
-// iteration in fp64 -- the same operation sequence the HIP kernel executes, fused
+// build, absent here).  Only its result matters -- the unit right singular vector of the
+// smallest singular value -- and it is restated two ways (column-pivoted QR + inverse
+// iteration with a one-sided Hestenes Jacobi fallback; Jacobi alone for RANSAC scoring)
+// in fp64 -- the same operation sequence the HIP kernel executes, fused
 // multiply-adds written explicitly and implicit contraction disabled on both sides -- and pinned two ways in
 // tests/test_oracle.py: (a) the reference's own test properties
 // (test/test_mvg.py:94-125: reprojection error < 1e-3 and X == X0 up to scale on
@@ -25,6 +27,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <utility>
 
 namespace {
 
@@ -35,17 +38,11 @@ struct Solve {
   double u, v, up, vp;
 };
 
-inline void dlt_solve(const double *P0, const double *P1, const double *x, const double *xp,
-                      Solve &out) {
-  const double u = x[0] / x[2], v = x[1] / x[2];
-  const double up = xp[0] / xp[2], vp = xp[1] / xp[2];
+// ---- null vector, method 1: one-sided (Hestenes) Jacobi, always converges ----------------
+inline void null_jacobi(const double (&A0)[4][4], double (&xv)[4]) {
   double A[4][4], V[4][4];
-  for (int c = 0; c < 4; ++c) {
-    A[0][c] = std::fma(u, P0[8 + c], -P0[0 + c]);
-    A[1][c] = std::fma(v, P0[8 + c], -P0[4 + c]);
-    A[2][c] = std::fma(up, P1[8 + c], -P1[0 + c]);
-    A[3][c] = std::fma(vp, P1[8 + c], -P1[4 + c]);
-  }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) A[r][c] = A0[r][c];
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
 
@@ -94,8 +91,98 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
       kbest = c;
     }
   }
-  double xv[4];
   for (int i = 0; i < 4; ++i) xv[i] = V[i][kbest];
+}
+
+// ---- null vector, method 2: column-pivoted Gram-Schmidt QR + inverse iteration -----------
+// A P = Q R; the smallest right singular vector of A is that of R (in pivoted order), found by
+// inverse iteration on R^T R (two triangular solves per step, contraction (sigma4/sigma3)^2).
+// `passes` x 4 steps; returns false when the last step still moved the vector by more than
+// 1e-12 (ill-separated sigma3, sigma4) -- the caller then falls back to method 1.
+inline bool null_qr_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
+  double col[4][4];  // col[c][r]
+  int perm[4] = {0, 1, 2, 3};
+  double R[4][4] = {{0}};
+  double ri[4];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) col[c][r] = A0[r][c];
+  double tiny = 0.0;
+  for (int j = 0; j < 4; ++j) {
+    double nn[4] = {0, 0, 0, 0};
+    for (int k = j; k < 4; ++k)
+      for (int r = 0; r < 4; ++r) nn[k] = std::fma(col[k][r], col[k][r], nn[k]);
+    int best = j;
+    for (int k = j + 1; k < 4; ++k)
+      if (nn[k] > nn[best]) best = k;
+    if (best != j) {
+      for (int r = 0; r < 4; ++r) std::swap(col[j][r], col[best][r]);
+      std::swap(perm[j], perm[best]);
+      std::swap(nn[j], nn[best]);
+      for (int r = 0; r < j; ++r) std::swap(R[r][j], R[r][best]);
+    }
+    double rjj = std::sqrt(nn[j]);
+    if (j == 0) tiny = 2.220446049250313e-16 * rjj;
+    if (!(rjj > tiny)) rjj = tiny;
+    R[j][j] = rjj;
+    ri[j] = 1.0 / rjj;
+    if (j < 3) {
+      double q[4];
+      for (int r = 0; r < 4; ++r) q[r] = col[j][r] * ri[j];
+      for (int k = j + 1; k < 4; ++k) {
+        double rjk = 0.0;
+        for (int r = 0; r < 4; ++r) rjk = std::fma(q[r], col[k][r], rjk);
+        R[j][k] = rjk;
+        for (int r = 0; r < 4; ++r) col[k][r] = std::fma(-rjk, q[r], col[k][r]);
+      }
+    }
+  }
+  double v[4] = {0.0, 0.0, 0.0, 1.0};
+  double delta = 1.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int it = 0; it < 4; ++it) {
+      // R^T z = v
+      const double z0 = v[0] * ri[0];
+      const double z1 = std::fma(-R[0][1], z0, v[1]) * ri[1];
+      const double z2 = std::fma(-R[1][2], z1, std::fma(-R[0][2], z0, v[2])) * ri[2];
+      const double z3 = std::fma(-R[2][3], z2, std::fma(-R[1][3], z1, std::fma(-R[0][3], z0, v[3]))) * ri[3];
+      // R w = z
+      const double w3 = z3 * ri[3];
+      const double w2 = std::fma(-R[2][3], w3, z2) * ri[2];
+      const double w1 = std::fma(-R[1][3], w3, std::fma(-R[1][2], w2, z1)) * ri[1];
+      const double w0 = std::fma(-R[0][3], w3, std::fma(-R[0][2], w2, std::fma(-R[0][1], w1, z0))) * ri[0];
+      const double nrm = std::sqrt(std::fma(w3, w3, std::fma(w2, w2, std::fma(w1, w1, w0 * w0))));
+      const double inv = 1.0 / nrm;
+      const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
+      delta = std::fmax(std::fmax(std::fabs(n0 - v[0]), std::fabs(n1 - v[1])),
+                        std::fmax(std::fabs(n2 - v[2]), std::fabs(n3 - v[3])));
+      v[0] = n0;
+      v[1] = n1;
+      v[2] = n2;
+      v[3] = n3;
+    }
+    if (delta <= 1e-12) break;
+  }
+  if (!(delta <= 1e-12)) return false;
+  for (int c = 0; c < 4; ++c) xv[perm[c]] = v[c];
+  return true;
+}
+
+// fast = true: method 2 with method 1 as fallback (dlt_triangulate / dlt_reprojection_error);
+// fast = false: method 1 only (RANSAC scoring, where most hypotheses are inconsistent and
+// method 2 would rarely converge).
+inline void dlt_solve(const double *P0, const double *P1, const double *x, const double *xp,
+                      Solve &out, bool fast = true) {
+  const double u = x[0] / x[2], v = x[1] / x[2];
+  const double up = xp[0] / xp[2], vp = xp[1] / xp[2];
+  double A[4][4];
+  for (int c = 0; c < 4; ++c) {
+    A[0][c] = std::fma(u, P0[8 + c], -P0[0 + c]);
+    A[1][c] = std::fma(v, P0[8 + c], -P0[4 + c]);
+    A[2][c] = std::fma(up, P1[8 + c], -P1[0 + c]);
+    A[3][c] = std::fma(vp, P1[8 + c], -P1[4 + c]);
+  }
+  double xv[4];
+  if (!(fast && null_qr_inverse_iteration(A, xv))) null_jacobi(A, xv);
   double nrm = 0.0;
   for (int i = 0; i < 4; ++i) nrm = std::fma(xv[i], xv[i], nrm);
   nrm = std::sqrt(nrm);
@@ -192,7 +279,7 @@ void oracle_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, 
     int cnt = 0;
     for (int i = 0; i < npt; ++i) {
       Solve s;
-      dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
+      dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s, /*fast=*/false);
       double r0[3], r1[3];
       reproject(P0, s.X, r0);
       reproject(P1, s.X, r1);

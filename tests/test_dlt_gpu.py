@@ -113,9 +113,12 @@ def test_score_hypotheses_matches_oracle(oracle):
     assert counts.argmax() == 0 and counts[0] > 0.8 * npt * 6 / 7
     assert np.array_equal(mvg.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2), counts)
     # the inlier definition, recomputed from the exported pieces
+    # (the exported error uses the QR + inverse-iteration solve, the scorer the Jacobi solve: equal
+    # to ~1e-15, so only points within 1e-9 of the threshold are excluded from this cross-check)
     err = mvg.dlt_reprojection_error(P0, P1s[0], x, xp)[:, 0]
     front = oracle.dlt_cheirality(P0, P1s[0], x, xp)
-    assert np.array_equal(mask[0], (err <= 1e-2) & front)
+    clear = np.abs(err - 1e-2) > 1e-9
+    assert np.array_equal(mask[0][clear], ((err <= 1e-2) & front)[clear])
 
 
 def test_many_camera_pairs_bit_exact(oracle):
