@@ -152,12 +152,13 @@ static int run_sharded(long long total, Fn fn) {
 
 namespace {
 
-// RAII device buffer for the host-pointer paths.
 // Per-device cache of freed device buffers for the host-pointer paths: repeated calls
 // (a front-end matching image pairs, RANSAC-style loops over dlt_triangulate) would
 // otherwise pay five hipMalloc/hipFree pairs each.  Grow-only up to kPoolCapBytes per
-// device; spv_release_cached_memory() empties it.  A buffer is returned to the pool only
-// after the call's stream has been synchronised, so reuse is safe without events.
+// device; spv_release_cached_memory() empties it.  A buffer goes back to the pool only after
+// the owning thread's stream has drained (DevBuf's destructor synchronises it: a no-op on the
+// normal path, which has already synchronised, and the safety net on error paths), so a
+// later owner on another stream never sees work in flight.
 class DevicePool {
  public:
   static constexpr size_t kPoolCapBytes = (size_t)4 << 30;
@@ -213,7 +214,9 @@ struct DevBuf {
   size_t cap = 0;
   int dev = 0;
   ~DevBuf() {
-    if (p) g_pool.release(dev, p, cap);
+    if (!p) return;
+    (void)hipStreamSynchronize(hipStreamPerThread);
+    g_pool.release(dev, p, cap);
   }
   int alloc(size_t bytes) {
     if (bytes == 0) bytes = 16;
