@@ -82,8 +82,8 @@ constexpr int kProjTile = kThreads * kProjRows;  // rows per workgroup
 constexpr int kProjChunk = 16;               // dims staged per step (dim % 16 == 0 always)
 constexpr int kProjXStride = kProjChunk * 4 + 16;  // bytes per row in LDS: 80 -> conflict-free b128 reads
 
-// NT tables are accumulated per pass over the rows (NT*2*MC accumulators per lane), so with
-// the default n = 2 the float32 rows are read from HBM exactly once.
+// NT tables are accumulated per pass over the rows (NT*2*MC accumulators per lane); NT = 1 is
+// the default (see launch_project), NT = 2 reads the float32 rows from HBM exactly once.
 template <int MC, int NT, bool IS_QUERY, int GMAX>
 __global__ __launch_bounds__(kThreads) void project_kernel(
     const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
@@ -773,7 +773,15 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G2>), grid, block, 0, stream, rows,  \
                        nrows, dim, m, n, g, dictp, codes, masks, img, counts, ranks, hbmask, nb);
   // two tables per pass while 2 x 2 x MC accumulators fit the register budget (MC <= 24)
-  const bool two = n >= 2;
+  // One table per pass by default: measured 0.57 ms against 0.65 ms for two tables per pass at
+  // 1M + 1M rows (both variants are LDS-limited to two workgroups per CU; the single-table pass
+  // re-reads the rows but has half the broadcast reads per staged step).
+  // SPECTAVI_CASCADE_NT=2 selects two tables per pass.
+  static const bool nt2_env = [] {
+    const char *e = getenv("SPECTAVI_CASCADE_NT");
+    return e && e[0] == '2';
+  }();
+  const bool two = n >= 2 && nt2_env;
 #define SPV_PROJECT_CASE(MCV)                                             \
   case MCV:                                                               \
     if (two && MCV <= 24) {                                               \
