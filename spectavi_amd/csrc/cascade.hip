@@ -65,25 +65,26 @@ __global__ void repack_dict_kernel(const float *__restrict__ dict, float *__rest
 }
 
 // ---------------------------------------------------------------------------------
-// 2/3. projections, codes, uint8 image.  A workgroup owns 512 rows, each lane two of
-// them.  Per 16-dim step the row tile is staged in LDS by coalesced 16-byte loads
+// 2/3. projections, codes, uint8 image.  A workgroup owns 256 rows, one per lane
+// (kProjRows).  Per 16-dim step the row tile is staged in LDS by coalesced 16-byte loads
 // (the uint8 image is written from the same registers), the hyperplanes of that step
 // are staged next to it and read by broadcast ds_read_b128 -- one LDS dword feeds
-// 64 lanes x 2 rows.  Accumulators of up to two tables x two rows stay in registers,
-// so float32 rows are read from HBM once.  The projection of (row, bit) is ONE
+// 64 lanes.  Accumulators of up to two tables stay in registers, so float32 rows are
+// read from HBM once.  The projection of (row, bit) is ONE
 // dim-ordered fp32 FMA chain (mirrored by the oracle).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2u8(float v) {
   return (uint32_t)((int)v + 128) & 0xFFu;  // trunc toward zero, wrap mod 256
 }
 
-constexpr int kProjRows = 2;                 // rows per lane (amortises the hyperplane broadcast)
+constexpr int kProjRows = 1;                 // rows per lane (2 halves the broadcast reads per FMA but its
+                                             // 77 KB of LDS allow only two workgroups per CU: measured slower)
 constexpr int kProjTile = kThreads * kProjRows;  // rows per workgroup
 constexpr int kProjChunk = 16;               // dims staged per step (dim % 16 == 0 always)
 constexpr int kProjXStride = kProjChunk * 4 + 16;  // bytes per row in LDS: 80 -> conflict-free b128 reads
 
-// NT tables are accumulated per pass over the rows (NT*2*MC accumulators per lane); NT = 1 is
-// the default (see launch_project), NT = 2 reads the float32 rows from HBM exactly once.
+// NT tables are accumulated per pass over the rows (NT*R*MC accumulators per lane); NT = 2 (the
+// default for n >= 2, see launch_project) reads the float32 rows from HBM exactly once.
 template <int MC, int NT, bool IS_QUERY, int GMAX>
 __global__ __launch_bounds__(kThreads) void project_kernel(
     const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
@@ -773,15 +774,15 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
     hipLaunchKernelGGL((project_kernel<MCV, NTV, IS_QUERY, G2>), grid, block, 0, stream, rows,  \
                        nrows, dim, m, n, g, dictp, codes, masks, img, counts, ranks, hbmask, nb);
   // two tables per pass while 2 x 2 x MC accumulators fit the register budget (MC <= 24)
-  // One table per pass by default: measured 0.57 ms against 0.65 ms for two tables per pass at
-  // 1M + 1M rows (both variants are LDS-limited to two workgroups per CU; the single-table pass
-  // re-reads the rows but has half the broadcast reads per staged step).
-  // SPECTAVI_CASCADE_NT=2 selects two tables per pass.
-  static const bool nt2_env = [] {
+  // Two tables per pass (rows read from HBM once) with one row per lane: 0.47 ms for 1M + 1M rows;
+  // measured alternatives: one table per pass 0.54 ms; two rows per lane 0.58 (one table) / 0.65
+  // (two tables) -- its 77 KB of LDS per workgroup halve the occupancy.
+  // SPECTAVI_CASCADE_NT=1 selects one table per pass.
+  static const bool nt1_env = [] {
     const char *e = getenv("SPECTAVI_CASCADE_NT");
-    return e && e[0] == '2';
+    return e && e[0] == '1';
   }();
-  const bool two = n >= 2 && nt2_env;
+  const bool two = n >= 2 && !nt1_env;
 #define SPV_PROJECT_CASE(MCV)                                             \
   case MCV:                                                               \
     if (two && MCV <= 24) {                                               \
