@@ -15,8 +15,8 @@
 //
 // The SVD itself lives in Eigen (JacobiSVD, version unpinned by the reference
 // build, absent here).  Only its result matters -- the unit right singular vector of the
-// smallest singular value -- and it is restated two ways (column-pivoted QR + inverse
-// iteration with a one-sided Hestenes Jacobi fallback; Jacobi alone for RANSAC scoring)
+// smallest singular value -- and it is restated two ways (square-root-free Gram-Schmidt +
+// inverse iteration with a one-sided Hestenes Jacobi fallback; Jacobi alone for RANSAC scoring)
 // in fp64 -- the same operation sequence the HIP kernel executes, fused
 // multiply-adds written explicitly and implicit contraction disabled on both sides -- and pinned two ways in
 // tests/test_oracle.py: (a) the reference's own test properties
@@ -94,78 +94,69 @@ inline void null_jacobi(const double (&A0)[4][4], double (&xv)[4]) {
   for (int i = 0; i < 4; ++i) xv[i] = V[i][kbest];
 }
 
-// ---- null vector, method 2: column-pivoted Gram-Schmidt QR + inverse iteration -----------
-// A P = Q R; the smallest right singular vector of A is that of R (in pivoted order), found by
-// inverse iteration on R^T R (two triangular solves per step, contraction (sigma4/sigma3)^2).
-// 2 to 8 steps; returns false when the last step still moved the vector by more than
-// 1e-12 (ill-separated sigma3, sigma4) -- the caller then falls back to method 1.
-inline bool null_qr_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
+// ---- null vector, method 2: square-root-free Gram-Schmidt + inverse iteration ------------
+// A = Q U with orthogonal (not normalised) columns q_j, d_j = |q_j|^2, U unit upper triangular
+// (modified Gram-Schmidt, no pivoting), so A^T A = U^T D U; the smallest right singular vector
+// of A by inverse iteration on U^T D U (two unit-triangular solves and a diagonal scaling per
+// step, contraction (sigma4/sigma3)^2, iterate kept at max-norm 1 from step 2 on).  4 to 8 steps; returns
+// false when the last step still moved the vector by more than 1e-12 (ill-separated sigma3,
+// sigma4, or inf/nan from a degenerate A) -- the caller then falls back to method 1.
+inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
   double col[4][4];  // col[c][r]
-  int perm[4] = {0, 1, 2, 3};
-  double R[4][4] = {{0}};
-  double ri[4];
+  double U[4][4] = {{0}};
+  double id[4];
   for (int c = 0; c < 4; ++c)
     for (int r = 0; r < 4; ++r) col[c][r] = A0[r][c];
-  double tiny = 0.0;
+  double tiny2 = 0.0;
   for (int j = 0; j < 4; ++j) {
-    double nn[4] = {0, 0, 0, 0};
-    for (int k = j; k < 4; ++k)
-      for (int r = 0; r < 4; ++r) nn[k] = std::fma(col[k][r], col[k][r], nn[k]);
-    int best = j;
-    for (int k = j + 1; k < 4; ++k)
-      if (nn[k] > nn[best]) best = k;
-    if (best != j) {
-      for (int r = 0; r < 4; ++r) std::swap(col[j][r], col[best][r]);
-      std::swap(perm[j], perm[best]);
-      std::swap(nn[j], nn[best]);
-      for (int r = 0; r < j; ++r) std::swap(R[r][j], R[r][best]);
-    }
-    double rjj = std::sqrt(nn[j]);
-    if (j == 0) tiny = 2.220446049250313e-16 * rjj;
-    if (!(rjj > tiny)) rjj = tiny;
-    R[j][j] = rjj;
-    ri[j] = 1.0 / rjj;
-    if (j < 3) {
-      double q[4];
-      for (int r = 0; r < 4; ++r) q[r] = col[j][r] * ri[j];
-      for (int k = j + 1; k < 4; ++k) {
-        double rjk = 0.0;
-        for (int r = 0; r < 4; ++r) rjk = std::fma(q[r], col[k][r], rjk);
-        R[j][k] = rjk;
-        for (int r = 0; r < 4; ++r) col[k][r] = std::fma(-rjk, q[r], col[k][r]);
-      }
+    double d = 0.0;
+    for (int r = 0; r < 4; ++r) d = std::fma(col[j][r], col[j][r], d);
+    if (j == 0) tiny2 = 4.930380657631324e-32 * d;  // eps^2 |a_0|^2
+    if (!(d > tiny2)) d = tiny2;
+    id[j] = 1.0 / d;
+    for (int k = j + 1; k < 4; ++k) {
+      double s = 0.0;
+      for (int r = 0; r < 4; ++r) s = std::fma(col[j][r], col[k][r], s);
+      const double u = s * id[j];
+      U[j][k] = u;
+      for (int r = 0; r < 4; ++r) col[k][r] = std::fma(-u, col[j][r], col[k][r]);
     }
   }
-  double v[4] = {0.0, 0.0, 0.0, 1.0};
+  // step 0 from e4 is a bare back-substitution, step 1 runs without normalisation; from step 2
+  // on the iterate is brought to max-norm 1 and tested (same schedule as the HIP kernel)
+  double v[4];
+  v[3] = 1.0;
+  v[2] = -U[2][3];
+  v[1] = std::fma(-U[1][2], v[2], -U[1][3]);
+  v[0] = std::fma(-U[0][1], v[1], std::fma(-U[0][2], v[2], -U[0][3]));
+  double w[4];
+  auto step = [&]() {  // w = (U^T D U)^-1 v
+    const double z0 = v[0];
+    const double z1 = std::fma(-U[0][1], z0, v[1]);
+    const double z2 = std::fma(-U[1][2], z1, std::fma(-U[0][2], z0, v[2]));
+    const double z3 = std::fma(-U[2][3], z2, std::fma(-U[1][3], z1, std::fma(-U[0][3], z0, v[3])));
+    const double y0 = z0 * id[0], y1 = z1 * id[1], y2 = z2 * id[2], y3 = z3 * id[3];
+    w[3] = y3;
+    w[2] = std::fma(-U[2][3], w[3], y2);
+    w[1] = std::fma(-U[1][3], w[3], std::fma(-U[1][2], w[2], y1));
+    w[0] = std::fma(-U[0][3], w[3], std::fma(-U[0][2], w[2], std::fma(-U[0][1], w[1], y0)));
+  };
+  step();
+  for (int c = 0; c < 4; ++c) v[c] = w[c];
   double delta = 1.0;
-  // at least 2, at most 8 steps; a point stops at the first step that moved its vector by no
-  // more than 1e-12 (noise-free points after 2, pixel noise 1e-3 after 3)
-  {
-    for (int it = 0; it < 8; ++it) {
-      // R^T z = v
-      const double z0 = v[0] * ri[0];
-      const double z1 = std::fma(-R[0][1], z0, v[1]) * ri[1];
-      const double z2 = std::fma(-R[1][2], z1, std::fma(-R[0][2], z0, v[2])) * ri[2];
-      const double z3 = std::fma(-R[2][3], z2, std::fma(-R[1][3], z1, std::fma(-R[0][3], z0, v[3]))) * ri[3];
-      // R w = z
-      const double w3 = z3 * ri[3];
-      const double w2 = std::fma(-R[2][3], w3, z2) * ri[2];
-      const double w1 = std::fma(-R[1][3], w3, std::fma(-R[1][2], w2, z1)) * ri[1];
-      const double w0 = std::fma(-R[0][3], w3, std::fma(-R[0][2], w2, std::fma(-R[0][1], w1, z0))) * ri[0];
-      const double nrm = std::sqrt(std::fma(w3, w3, std::fma(w2, w2, std::fma(w1, w1, w0 * w0))));
-      const double inv = 1.0 / nrm;
-      const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
-      delta = std::fmax(std::fmax(std::fabs(n0 - v[0]), std::fabs(n1 - v[1])),
-                        std::fmax(std::fabs(n2 - v[2]), std::fabs(n3 - v[3])));
-      v[0] = n0;
-      v[1] = n1;
-      v[2] = n2;
-      v[3] = n3;
-      if (it >= 1 && delta <= 1e-12) break;
-    }
+  for (int it = 2; it < 8; ++it) {
+    step();
+    const double big = std::fmax(std::fmax(std::fabs(w[0]), std::fabs(w[1])), std::fmax(std::fabs(w[2]), std::fabs(w[3])));
+    const double inv = 1.0 / big;
+    double n[4];
+    for (int c = 0; c < 4; ++c) n[c] = w[c] * inv;
+    delta = std::fmax(std::fmax(std::fabs(n[0] - v[0]), std::fabs(n[1] - v[1])),
+                      std::fmax(std::fabs(n[2] - v[2]), std::fabs(n[3] - v[3])));
+    for (int c = 0; c < 4; ++c) v[c] = n[c];
+    if (delta <= 1e-12) break;
   }
   if (!(delta <= 1e-12)) return false;
-  for (int c = 0; c < 4; ++c) xv[perm[c]] = v[c];
+  for (int c = 0; c < 4; ++c) xv[c] = v[c];
   return true;
 }
 
@@ -184,7 +175,7 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
     A[3][c] = std::fma(vp, P1[8 + c], -P1[4 + c]);
   }
   double xv[4];
-  if (!(fast && null_qr_inverse_iteration(A, xv))) null_jacobi(A, xv);
+  if (!(fast && null_gs_inverse_iteration(A, xv))) null_jacobi(A, xv);
   double nrm = 0.0;
   for (int i = 0; i < 4; ++i) nrm = std::fma(xv[i], xv[i], nrm);
   nrm = std::sqrt(nrm);
@@ -197,8 +188,8 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
     neg = xv[1] < 0.0;
   else
     neg = xv[2] < 0.0;
-  const double scale = neg ? -nrm : nrm;
-  for (int i = 0; i < 4; ++i) out.X[i] = xv[i] / scale;
+  const double scale = 1.0 / (neg ? -nrm : nrm);
+  for (int i = 0; i < 4; ++i) out.X[i] = xv[i] * scale;
   out.u = u;
   out.v = v;
   out.up = up;

@@ -3,12 +3,12 @@
 // Replaces the reference's serial per-point loop (src/Spectavi.cpp:48-51, :64-67)
 // around DltTriangulator::solve / reprojection_error
 // (src/DltTriangulator.h:36-74).  The reference runs Eigen::JacobiSVD on a
-// heap-allocated dynamic 4x4 per point; here one lane owns one point and the
+// heap-allocated dynamic 4x4 per point; here one lane owns one point at a time and the
 // whole 4x4 problem lives in registers (fp64):
 //
 //   A = [u P0[2]-P0[0]; v P0[2]-P0[1]; u' P1[2]-P1[0]; v' P1[2]-P1[1]]   (:51-54)
 //   X = right singular vector of the smallest singular value = V.col(3) of the
-//   reference (:56-58), by column-pivoted QR + inverse iteration (~700 fp64
+//   reference (:56-58), by square-root-free Gram-Schmidt + inverse iteration (~400 fp64
 //   instructions) with a one-sided (Hestenes) Jacobi fallback (~3100, always
 //   converges; right rotations orthogonalise the columns of A, V accumulates them,
 //   the column of smallest norm is the answer).
@@ -21,6 +21,8 @@
 // X[3] >= 0 (first nonzero component positive when X[3] == 0).
 
 #include "common.h"
+
+#include <atomic>
 
 namespace spv {
 namespace {
@@ -103,113 +105,90 @@ __device__ __forceinline__ void null_jacobi(const double (&A0)[4][4], double (&x
     xv[i] = kbest == 0 ? V[i][0] : (kbest == 1 ? V[i][1] : (kbest == 2 ? V[i][2] : V[i][3]));
 }
 
-// ---- null vector, method 2: column-pivoted Gram-Schmidt QR + inverse iteration -----------
-// A P = Q R; the smallest right singular vector of A is that of R (in pivoted order), found by
-// inverse iteration on R^T R: two triangular solves per step, contraction (sigma4/sigma3)^2,
-// 450-700 fp64 instructions against about 3000 for method 1.  Returns false when the last
-// of up to 8 steps still moved the vector by more than 1e-12 (ill-separated sigma3, sigma4);
-// the caller then falls back to method 1.  Operation order mirrors the oracle exactly.
-__device__ __forceinline__ bool null_qr_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
+// ---- null vector, method 2: square-root-free Gram-Schmidt + inverse iteration ------------
+// A = Q U with orthogonal (not normalised) columns q_j, d_j = |q_j|^2 and U unit upper
+// triangular (modified Gram-Schmidt, no pivoting: only U and d are used, and those are
+// backward stable whatever the column order), so A^T A = U^T D U.  The smallest right singular
+// vector of A is found by inverse iteration on U^T D U: two unit-triangular solves and one
+// diagonal scaling per step, contraction (sigma4/sigma3)^2; the iterate is kept at max-norm 1
+// (one division, no square root).  About 450 fp64 instructions for 4 steps against about 3000
+// for method 1.  Returns false when the last of up to 8 steps still moved the vector by more
+// than 1e-12 (ill-separated sigma3, sigma4, or a degenerate A that produced inf/nan); the
+// caller then falls back to method 1.  Operation order mirrors the oracle exactly.
+__device__ __forceinline__ bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
   double col[4][4];  // col[c][r]
-  int perm[4] = {0, 1, 2, 3};
-  double R[4][4];
-  double ri[4];
+  double U[4][4];    // strictly upper part used
+  double id[4];      // 1 / d_j
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      col[c][r] = A0[r][c];
-      R[c][r] = 0.0;
-    }
-  double tiny = 0.0;
+    for (int r = 0; r < 4; ++r) col[c][r] = A0[r][c];
+  double tiny2 = 0.0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    double nn[4] = {0.0, 0.0, 0.0, 0.0};
+    double d = 0.0;
 #pragma unroll
-    for (int k = j; k < 4; ++k)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) nn[k] = __builtin_fma(col[k][r], col[k][r], nn[k]);
-    // pivot: the remaining column of largest norm (lowest index on ties) moves to position j
-    int best = j;
-    double nb = nn[j];
+    for (int r = 0; r < 4; ++r) d = __builtin_fma(col[j][r], col[j][r], d);
+    if (j == 0) tiny2 = 4.930380657631324e-32 * d;  // eps^2 |a_0|^2
+    if (!(d > tiny2)) d = tiny2;
+    id[j] = 1.0 / d;
 #pragma unroll
     for (int k = j + 1; k < 4; ++k) {
-      const bool g = nn[k] > nb;
-      best = g ? k : best;
-      nb = g ? nn[k] : nb;
-    }
+      double s = 0.0;
 #pragma unroll
-    for (int k = j + 1; k < 4; ++k) {
-      const bool sw = best == k;
+      for (int r = 0; r < 4; ++r) s = __builtin_fma(col[j][r], col[k][r], s);
+      const double u = s * id[j];
+      U[j][k] = u;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double a = col[j][r], c = col[k][r];
-        col[j][r] = sw ? c : a;
-        col[k][r] = sw ? a : c;
-      }
-      const int pj = perm[j], pk = perm[k];
-      perm[j] = sw ? pk : pj;
-      perm[k] = sw ? pj : pk;
-#pragma unroll
-      for (int r = 0; r < j; ++r) {
-        const double a = R[r][j], c = R[r][k];
-        R[r][j] = sw ? c : a;
-        R[r][k] = sw ? a : c;
-      }
-    }
-    double rjj = sqrt(nb);
-    if (j == 0) tiny = 2.220446049250313e-16 * rjj;
-    if (!(rjj > tiny)) rjj = tiny;
-    R[j][j] = rjj;
-    ri[j] = 1.0 / rjj;
-    if (j < 3) {
-      double q[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] = col[j][r] * ri[j];
-#pragma unroll
-      for (int k = j + 1; k < 4; ++k) {
-        double rjk = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rjk = __builtin_fma(q[r], col[k][r], rjk);
-        R[j][k] = rjk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) col[k][r] = __builtin_fma(-rjk, q[r], col[k][r]);
-      }
+      for (int r = 0; r < 4; ++r) col[k][r] = __builtin_fma(-u, col[j][r], col[k][r]);
     }
   }
-  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 1.0;
+  // step 0 from e4 is a bare back-substitution (U^T e4 = e4, the diagonal scaling only changes
+  // the length), step 1 runs without normalisation; from step 2 on the iterate is brought to
+  // max-norm 1 and a point stops at the first step that moved it by no more than 1e-12
+  // (step 3 for pixel noise around 1e-3; at most 8 steps)
+  double v3 = 1.0;
+  double v2 = -U[2][3];
+  double v1 = __builtin_fma(-U[1][2], v2, -U[1][3]);
+  double v0 = __builtin_fma(-U[0][1], v1, __builtin_fma(-U[0][2], v2, -U[0][3]));
+  double w0, w1, w2, w3;
+  auto step = [&]() {  // w = (U^T D U)^-1 v
+    // U^T z = v
+    const double z0 = v0;
+    const double z1 = __builtin_fma(-U[0][1], z0, v1);
+    const double z2 = __builtin_fma(-U[1][2], z1, __builtin_fma(-U[0][2], z0, v2));
+    const double z3 = __builtin_fma(-U[2][3], z2, __builtin_fma(-U[1][3], z1, __builtin_fma(-U[0][3], z0, v3)));
+    // D y = z
+    const double y0 = z0 * id[0], y1 = z1 * id[1], y2 = z2 * id[2], y3 = z3 * id[3];
+    // U w = y
+    w3 = y3;
+    w2 = __builtin_fma(-U[2][3], w3, y2);
+    w1 = __builtin_fma(-U[1][3], w3, __builtin_fma(-U[1][2], w2, y1));
+    w0 = __builtin_fma(-U[0][3], w3, __builtin_fma(-U[0][2], w2, __builtin_fma(-U[0][1], w1, y0)));
+  };
+  step();
+  v0 = w0;
+  v1 = w1;
+  v2 = w2;
+  v3 = w3;
   double delta = 1.0;
-  // at least 2, at most 8 steps; a point stops at the first step that moved its vector by no
-  // more than 1e-12 (noise-free points after 2, pixel noise 1e-3 after 3)
-  {
-    for (int it = 0; it < 8; ++it) {
-      // R^T z = v
-      const double z0 = v0 * ri[0];
-      const double z1 = __builtin_fma(-R[0][1], z0, v1) * ri[1];
-      const double z2 = __builtin_fma(-R[1][2], z1, __builtin_fma(-R[0][2], z0, v2)) * ri[2];
-      const double z3 =
-          __builtin_fma(-R[2][3], z2, __builtin_fma(-R[1][3], z1, __builtin_fma(-R[0][3], z0, v3))) * ri[3];
-      // R w = z
-      const double w3 = z3 * ri[3];
-      const double w2 = __builtin_fma(-R[2][3], w3, z2) * ri[2];
-      const double w1 = __builtin_fma(-R[1][3], w3, __builtin_fma(-R[1][2], w2, z1)) * ri[1];
-      const double w0 =
-          __builtin_fma(-R[0][3], w3, __builtin_fma(-R[0][2], w2, __builtin_fma(-R[0][1], w1, z0))) * ri[0];
-      const double nrm = sqrt(__builtin_fma(w3, w3, __builtin_fma(w2, w2, __builtin_fma(w1, w1, w0 * w0))));
-      const double inv = 1.0 / nrm;
-      const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
-      delta = fmax(fmax(fabs(n0 - v0), fabs(n1 - v1)), fmax(fabs(n2 - v2), fabs(n3 - v3)));
-      v0 = n0;
-      v1 = n1;
-      v2 = n2;
-      v3 = n3;
-      if (it >= 1 && delta <= 1e-12) break;
-    }
+  for (int it = 2; it < 8; ++it) {
+    step();
+    const double big = fmax(fmax(fabs(w0), fabs(w1)), fmax(fabs(w2), fabs(w3)));
+    const double inv = 1.0 / big;
+    const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
+    delta = fmax(fmax(fabs(n0 - v0), fabs(n1 - v1)), fmax(fabs(n2 - v2), fabs(n3 - v3)));
+    v0 = n0;
+    v1 = n1;
+    v2 = n2;
+    v3 = n3;
+    if (delta <= 1e-12) break;
   }
   if (!(delta <= 1e-12)) return false;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    xv[t] = perm[0] == t ? v0 : (perm[1] == t ? v1 : (perm[2] == t ? v2 : v3));
+  xv[0] = v0;
+  xv[1] = v1;
+  xv[2] = v2;
+  xv[3] = v3;
   return true;
 }
 
@@ -235,7 +214,7 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
   }
   double xv[4];
   bool done = false;
-  if (FAST) done = null_qr_inverse_iteration(A, xv);
+  if (FAST) done = null_gs_inverse_iteration(A, xv);
   if (!done) null_jacobi(A, xv);
   // renormalise (V is orthogonal up to rounding) and canonicalise the sign
   double nrm = 0.0;
@@ -251,51 +230,67 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
     neg = xv[1] < 0.0;
   else
     neg = xv[2] < 0.0;
-  const double scale = neg ? -nrm : nrm;
+  const double scale = 1.0 / (neg ? -nrm : nrm);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) X[i] = xv[i] / scale;
+  for (int i = 0; i < 4; ++i) X[i] = xv[i] * scale;
 }
 
+// Persistent, barrier-free: every lane walks the points p, p + stride, ... and loads the six
+// input doubles of its next point before solving the current one, so the HBM stream (a wave
+// covers 64 x 24 contiguous bytes per view, 64 x 32 on the way out) overlaps the fp64 work of the
+// same wave instead of relying on other workgroups' phases (measured on 10M points: 0.208 ms with
+// one LDS-staged tile per workgroup, 0.178 ms this way; memory pattern alone 0.143 ms, solve
+// alone 0.127 ms).
 template <bool WANT_ERROR>
 __global__ __launch_bounds__(kDltThreads) void dlt_kernel(Cameras cam, long long npt,
                                                           const double *__restrict__ x,
                                                           const double *__restrict__ xp,
                                                           double *__restrict__ dst) {
-  // coalesced staging: the block's 256 points are 256*3 contiguous doubles per view
-  __shared__ double sx[kDltThreads * 3];
-  __shared__ double sxp[kDltThreads * 3];
-  const long long base = (long long)blockIdx.x * kDltThreads;
-  const long long nblk = min((long long)kDltThreads, npt - base);
-  for (int e = threadIdx.x; e < nblk * 3; e += kDltThreads) {
-    sx[e] = x[base * 3 + e];
-    sxp[e] = xp[base * 3 + e];
+  const long long stride = (long long)gridDim.x * kDltThreads;
+  long long p = (long long)blockIdx.x * kDltThreads + threadIdx.x;
+  double a0 = 1.0, a1 = 1.0, a2 = 1.0, b0 = 1.0, b1 = 1.0, b2 = 1.0;
+  if (p < npt) {
+    a0 = x[3 * p];
+    a1 = x[3 * p + 1];
+    a2 = x[3 * p + 2];
+    b0 = xp[3 * p];
+    b1 = xp[3 * p + 1];
+    b2 = xp[3 * p + 2];
   }
-  __syncthreads();
-  const int t = threadIdx.x;
-  if (t >= nblk) return;
-  double X[4], u, v, up, vp;
-  dlt_solve<true>(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1],
-                  sxp[3 * t + 2], X, u, v, up, vp);
-  if (!WANT_ERROR) {
-    double4 *o = reinterpret_cast<double4 *>(dst) + (base + t);
-    *o = make_double4(X[0], X[1], X[2], X[3]);
-  } else {
-    // reference src/DltTriangulator.h:61-62, 67-74
-    double r0[3], r1[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
-        b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
-      }
-      r0[r] = a;
-      r1[r] = b;
+  for (; p < npt; p += stride) {
+    const double c0 = a0, c1 = a1, c2 = a2, d0 = b0, d1 = b1, d2 = b2;
+    const long long q = p + stride;
+    if (q < npt) {
+      a0 = x[3 * q];
+      a1 = x[3 * q + 1];
+      a2 = x[3 * q + 2];
+      b0 = xp[3 * q];
+      b1 = xp[3 * q + 1];
+      b2 = xp[3 * q + 2];
     }
-    const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
-    const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
-    dst[base + t] = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
+    double X[4], u, v, up, vp;
+    dlt_solve<true>(cam, c0, c1, c2, d0, d1, d2, X, u, v, up, vp);
+    if (!WANT_ERROR) {
+      double4 *o = reinterpret_cast<double4 *>(dst) + p;
+      *o = make_double4(X[0], X[1], X[2], X[3]);
+    } else {
+      // reference src/DltTriangulator.h:61-62, 67-74
+      double r0[3], r1[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
+          b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
+        }
+        r0[r] = a;
+        r1[r] = b;
+      }
+      const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
+      const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
+      dst[p] = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
+    }
   }
 }
 
@@ -401,8 +396,16 @@ int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x
     cam.p0[i] = P0[i];
     cam.p1[i] = P1[i];
   }
-  const long long blocks = (npt + kDltThreads - 1) / kDltThreads;
-  if (blocks > 0x7FFFFFFFLL) return set_error(SPV_ERR_INVALID, "too many points");
+  // persistent grid: at most 32 workgroups per CU, each lane strides over its points
+  static std::atomic<int> cu_count[64];  // per device, 0 = not asked yet
+  int dev = 0;
+  SPV_HIP_CHECK(hipGetDevice(&dev));
+  int cus = (dev >= 0 && dev < 64) ? cu_count[dev].load(std::memory_order_relaxed) : 0;
+  if (cus <= 0) {
+    SPV_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cu_count[dev].store(cus, std::memory_order_relaxed);
+  }
+  const long long blocks = std::min<long long>((npt + kDltThreads - 1) / kDltThreads, (long long)std::max(cus, 1) * 32);
   ProfScope prof("dlt", stream);
   if (want_error)
     hipLaunchKernelGGL((dlt_kernel<true>), dim3((unsigned)blocks), dim3(kDltThreads), 0, stream,

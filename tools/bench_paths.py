@@ -230,10 +230,17 @@ if __name__ == "__main__":
     ap.add_argument("--npt", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--only", default="", help="comma list of: cascade,dlt,next,shapes,e2e (default all)")
     a = ap.parse_args()
-    cascade(a.rows, a.steps, a.warmup, planted=False)
-    cascade(a.rows, a.steps, a.warmup, planted=True)
-    dlt(a.npt, a.steps, a.warmup)
-    next_rows(a.steps, a.warmup)
-    l1k2_shapes(a.steps, a.warmup)
-    end_to_end()
+    want = set(filter(None, a.only.split(",")))
+    if not want or "cascade" in want:
+        cascade(a.rows, a.steps, a.warmup, planted=False)
+        cascade(a.rows, a.steps, a.warmup, planted=True)
+    if not want or "dlt" in want:
+        dlt(a.npt, a.steps, a.warmup)
+    if not want or "next" in want:
+        next_rows(a.steps, a.warmup)
+    if not want or "shapes" in want:
+        l1k2_shapes(a.steps, a.warmup)
+    if not want or "e2e" in want:
+        end_to_end()
