@@ -92,8 +92,8 @@ int gather_match_coords_run(const float *d_geom_x, const float *d_geom_y, const 
 //   x0      = x - mean_c;  norm_c = max(max(x0), -min(x0))
 //   out     = clip(rint(x0 / norm_c * 128), -128, 127), zero-padded to a multiple of 16 columns
 // The column sums are inherently serial in the rows (float addition is not associative), so the
-// statistics kernel parallelises over 16-column blocks only -- one workgroup each, all lanes
-// streaming row tiles into LDS, 16 lanes running the chains; everything else is parallel.  Optionally
+// statistics kernel parallelises over 16-column blocks only -- one workgroup each, four waves
+// streaming row tiles into LDS, 16 lanes of a fifth running the chains; everything else is parallel.  Optionally
 // also emits the +128 uint8 image the brute-force path takes
 // (example/ex01_essential_estimation.py:96-99).
 // ---------------------------------------------------------------------------------
@@ -103,68 +103,92 @@ namespace {
 constexpr int kStatCols = 16;   // columns per workgroup: one 64-byte sector of every row
 constexpr int kStatRows = 512;  // rows per LDS tile (double buffered: 2 x 32 KB)
 
-// One workgroup per block of 16 columns.  All 256 lanes stream the block's row tiles into
-// LDS (register-prefetched, one tile ahead); lanes 0..15 of wave 0 then run the serial
-// per-column chains over the tile in row order: s += v (float32, exactly numpy's order),
-// running max and min.  stats[0][c] = mean, stats[1][c] = max(max - mean, -(min - mean)).
-__global__ __launch_bounds__(256) void column_stats_kernel(const float *__restrict__ x, int rows,
-                                                           int dim, float *__restrict__ stats) {
+// One workgroup of five waves per block of 16 columns.  Waves 1..4 (256 lanes) stream the
+// block's row tiles into LDS, register-prefetched one tile ahead, and fold max / min of what
+// they load (order-independent).  Wave 0 does nothing but the serial per-column chains, lanes
+// 0..15, over the tile the loaders finished in the previous round: s += v in row order
+// (float32, exactly numpy's order), its LDS reads issued one 16-row batch ahead of the adds so
+// the chain runs at the dependent-add rate.  One barrier per tile; the loaders' round (LDS
+// writes + issuing the next prefetch) hides behind the chain's.
+// stats[0][c] = mean, stats[1][c] = max(max - mean, -(min - mean)).
+constexpr int kStatThreads = 320;
+__global__ __launch_bounds__(kStatThreads) void column_stats_kernel(const float *__restrict__ x, int rows,
+                                                                    int dim, float *__restrict__ stats) {
   __shared__ float tile[2][kStatRows * kStatCols];  // [row][column]
-  constexpr int NL = kStatRows * kStatCols / 256;  // 32 floats per lane per tile
+  constexpr int NL = kStatRows * kStatCols / 256;   // 32 floats per loader lane per tile
   const int t = threadIdx.x;
+  const bool loader = t >= 64;
+  const int lt = t - 64;
   const int c0 = blockIdx.x * kStatCols;
   const int ncol = min(kStatCols, dim - c0);
-  const int col = t & 15, rsub = t >> 4;  // lane -> (column, row within a group of 16 rows)
-  float pre[NL];
-  auto prefetch = [&](int row0) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int r = row0 + rsub + 16 * i;
-      pre[i] = (r < rows && col < ncol) ? x[(size_t)r * dim + c0 + col] : 0.f;
-    }
-  };
-  // max / min are order-independent: every lane folds the values it loads itself; only the
-  // float32 sum needs the row-ordered serial chain (lanes 0..15)
-  float s = 0.f, mx = -__builtin_inff(), mn = __builtin_inff();
+  const int col = lt & 15, rsub = lt >> 4;  // loader lane -> (column, row within a group of 16 rows)
   const int ntiles = (rows + kStatRows - 1) / kStatRows;
-  auto fold_minmax = [&](int row0) {
+  float pre[NL];
+  float s = 0.f, mx = -__builtin_inff(), mn = __builtin_inff();
+  const int colc = min(col, ncol - 1);
+  auto prefetch = [&](int row0) {  // clamped addresses, raw values: nothing here waits for the loads
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      if (row0 + rsub + 16 * i < rows) {
-        mx = fmaxf(mx, pre[i]);
-        mn = fminf(mn, pre[i]);
-      }
-    }
+    for (int i = 0; i < NL; ++i)
+      pre[i] = x[(size_t)min(row0 + rsub + 16 * i, rows - 1) * dim + c0 + colc];
   };
-  if (ntiles > 0) prefetch(0);
-  for (int tl = 0; tl < ntiles; ++tl) {
+  auto publish = [&](int tl) {  // registers -> LDS tile tl, folding max / min on the way
     float *buf = tile[tl & 1];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) buf[(rsub + 16 * i) * kStatCols + col] = pre[i];
-    fold_minmax(tl * kStatRows);
-    __syncthreads();  // tile tl is complete; tile tl-1's chain finished before its own barrier
-    if (tl + 1 < ntiles) prefetch((tl + 1) * kStatRows);
-    if (t < kStatCols) {
-      const int nr = min(kStatRows, rows - tl * kStatRows);
-      int r = 0;
-      for (; r + 16 <= nr; r += 16) {
-        float v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = buf[(r + k) * kStatCols + t];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += v[k];  // strictly in row order
-      }
-      for (; r < nr; ++r) s += buf[r * kStatCols + t];
+    for (int i = 0; i < NL; ++i) {
+      // rows past the end and columns past the block become +0 (bitwise, so the load above
+      // stays unconditional and the 32 of them stay in flight together)
+      const bool live = tl * kStatRows + rsub + 16 * i < rows && col < ncol;
+      const float v = __uint_as_float(__float_as_uint(pre[i]) & (live ? 0xFFFFFFFFu : 0u));
+      buf[(rsub + 16 * i) * kStatCols + col] = v;
+      mx = live ? fmaxf(mx, v) : mx;
+      mn = live ? fminf(mn, v) : mn;
     }
-    // the next iteration writes the OTHER buffer; this buffer is rewritten two iterations
-    // later, after the barrier of the next iteration, which the chain lanes reach only
-    // once they are done reading it
+  };
+  if (loader && ntiles > 0) {
+    prefetch(0);
+    publish(0);
+    if (ntiles > 1) prefetch(kStatRows);
+  }
+  __syncthreads();
+  for (int tl = 0; tl < ntiles; ++tl) {
+    if (loader) {
+      // tile tl + 1 goes into the buffer the chain finished with before the last barrier
+      if (tl + 1 < ntiles) {
+        publish(tl + 1);
+        if (tl + 2 < ntiles) prefetch((tl + 2) * kStatRows);
+      }
+    } else if (t < kStatCols) {
+      // rows past the end of the input were published as +0, which leaves a float32 sum
+      // unchanged, so every tile is walked in full: 16 batches of 32 rows, no conditionals.
+      // The scheduling barriers pin "reads of the next half-batch, then adds of this one".
+      const float *buf = tile[tl & 1] + t;
+      float va[16], vb[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) va[k] = buf[k * kStatCols];
+      for (int r = 0; r < kStatRows; r += 32) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) vb[k] = buf[(r + 16 + k) * kStatCols];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += va[k];  // strictly in row order
+        __builtin_amdgcn_sched_barrier(0);
+        const int rn = (r + 32) & (kStatRows - 1);  // the last round re-reads rows 0..15, unused
+#pragma unroll
+        for (int k = 0; k < 16; ++k) va[k] = buf[(rn + k) * kStatCols];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += vb[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
   }
   // combine the 16 row-groups' max / min per column
-  __syncthreads();
   float *red = tile[0];
-  red[t] = mx;
-  red[256 + t] = mn;
+  if (loader) {
+    red[lt] = mx;
+    red[256 + lt] = mn;
+  }
   __syncthreads();
   if (t < ncol) {
     float cmx = red[t], cmn = red[256 + t];
@@ -212,7 +236,7 @@ int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigne
   float *stats = static_cast<float *>(d_ws);
   const int dim16 = (dim + 15) / 16 * 16;
   ProfScope prof("normalize", stream);
-  hipLaunchKernelGGL(column_stats_kernel, dim3((dim + kStatCols - 1) / kStatCols), dim3(256), 0, stream, d_x,
+  hipLaunchKernelGGL(column_stats_kernel, dim3((dim + kStatCols - 1) / kStatCols), dim3(kStatThreads), 0, stream, d_x,
                      rows, dim, stats);
   hipLaunchKernelGGL(normalize_apply_kernel, dim3(2048), dim3(256), 0, stream, d_x, rows, dim, dim16, stats,
                      d_out_f32, d_out_u8);

@@ -54,7 +54,7 @@ def test_real_descriptors_l1k2_and_pipeline(oracle, golden):
     assert np.array_equal(x1h[:, :2], t2[m[:, 0], :2].astype(np.float64)) and np.all(x1h[:, 2] == 1)
 
 
-@pytest.mark.parametrize("rows,dim,seed", [(1168, 132, 0), (200, 144, 1), (5000, 128, 2), (33, 7, 3), (100003, 132, 4)])
+@pytest.mark.parametrize("rows,dim,seed", [(1168, 132, 0), (200, 144, 1), (5000, 128, 2), (33, 7, 3), (100003, 132, 4), (1576, 20, 5), (1047, 16, 6)])
 def test_normalize_bit_identical_to_numpy(golden, rows, dim, seed):
     """Device normalisation == the numpy front-end function (reference spectavi/feature.py:384-407)
     bit for bit on float32 input, including the real SIFT table (all 132 columns, as the

@@ -126,6 +126,48 @@ def end_to_end():
                       "config": {"workload": "256k x 256k D=128, numpy in / numpy out"}, "dtype": "u8",
                       "data": "synthetic"}), flush=True)
 
+    # BASELINE configs[2] and [3] through the same boundary: 1 GB of float32 in for the cascade,
+    # 480 MB in / 320 MB out for the triangulation
+    from spectavi_amd import mvg
+    rows = 1_000_000
+    xf = rng.integers(0, 256, (rows, 128), dtype=np.uint8).astype(np.float32) - 128
+    yf = rng.integers(0, 256, (rows, 128), dtype=np.uint8).astype(np.float32) - 128
+    m = feature.auto_hash_bit_rate(rows, rows)
+    d = feature.generate_hash_dict(0x5eed, 128, m, 2)
+    feature.nn_cascading_hash_with_dict(xf[:4096], yf[:4096], d[:, :, :6].copy(), g=2)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        feature.nn_cascading_hash_with_dict(xf, yf, d, g=2)
+        best = min(best, time.perf_counter() - t0)
+    print(json.dumps({"metric": "nn_cascading_hash through the host-pointer C-ABI (PCIe-inclusive), queries/s",
+                      "value": rows / best, "unit": "queries/s", "ms_per_step": best * 1e3,
+                      "config": {"workload": "cascade 1M x 1M D=128 m=%d n=2 g=2, numpy float32 in / numpy out" % m,
+                                 "host_bytes_in": int(xf.nbytes + yf.nbytes), "host_bytes_out": rows * 24},
+                      "dtype": "f32 hash + u8 refine", "data": "synthetic"}), flush=True)
+    del xf, yf
+    npt = 10_000_000
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    R, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    P1 = np.hstack([R, rng.standard_normal((3, 1))])
+    Xw = rng.standard_normal((npt, 4))
+    Xw[:, 2] += 5.0
+    Xw[:, 3] = 1.0
+    px = np.ascontiguousarray(Xw @ P0.T)
+    pxp = np.ascontiguousarray(Xw @ P1.T)
+    mvg.dlt_triangulate(P0, P1, px[:1000], pxp[:1000])
+    for name, fn, out_b in (("dlt_triangulate", mvg.dlt_triangulate, 32), ("dlt_reprojection_error", mvg.dlt_reprojection_error, 8)):
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn(P0, P1, px, pxp)
+            best = min(best, time.perf_counter() - t0)
+        print(json.dumps({"metric": "%s through the host-pointer C-ABI (PCIe-inclusive), points/s" % name,
+                          "value": npt / best, "unit": "points/s", "ms_per_step": best * 1e3,
+                          "config": {"workload": "%s 10M points, numpy float64 in / numpy out" % name,
+                                     "host_bytes_in": int(px.nbytes + pxp.nbytes), "host_bytes_out": npt * out_b},
+                          "dtype": "f64", "data": "synthetic"}), flush=True)
+
 
 def l1k2_shapes(steps, warmup):
     """Other descriptor widths and small problems (device-resident, kernel + merge)."""
