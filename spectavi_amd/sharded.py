@@ -1,6 +1,7 @@
-"""Query-sharded L1 2-NN across the GPUs of one node: one process per GPU,
-`torch.distributed` (backend "nccl" = RCCL over xGMI), results collected with
-one gather of packed (idx0, idx1, d0, d1) records.
+"""The hot path sharded across the GPUs of one node: one process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI).  L1 2-NN and cascade hash shard the
+queries and collect packed (idx0, idx1, d0, d1) records with one gather; DLT shards the
+correspondences and gathers 32 bytes per point.
 
 Every query row is independent (the reference parallelises exactly this loop
 with OpenMP, src/BruteForceNnL1K2.h:92-93), so the only exchange step is the
@@ -36,6 +37,32 @@ def _default_local_fn(x, y):
     return device.l1k2(x, y)
 
 
+def gather_rows(local, total_rows, group=None, dst=0):
+    """Gather row-sharded results on rank `dst`: every rank passes its [hi - lo, k] tensor
+    (shard_bounds order); ragged shards are padded to the largest so all ranks send the same
+    count (one collective, no size exchange).  Returns the [total_rows, k] tensor on `dst`,
+    None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(total_rows, world, rank)
+    assert local.shape[0] == hi - lo, "local rows do not match shard_bounds"
+    max_rows = shard_bounds(total_rows, world, 0)[1]
+    send = local.contiguous()
+    if send.shape[0] < max_rows:
+        pad = torch.zeros((max_rows - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad], dim=0)
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=bufs, dst=dst, group=group)
+        parts = []
+        for r in range(world):
+            rlo, rhi = shard_bounds(total_rows, world, r)
+            parts.append(bufs[r][: rhi - rlo])
+        return torch.cat(parts, dim=0)
+    dist.gather(send, gather_list=None, dst=dst, group=group)
+    return None
+
+
 def nn_bruteforcel1k2_sharded(x, y_shard, total_queries, group=None, dst=0, local_fn=None):
     """Run the local shard and gather all shards' results on rank `dst`.
 
@@ -46,24 +73,42 @@ def nn_bruteforcel1k2_sharded(x, y_shard, total_queries, group=None, dst=0, loca
     Returns (idx, dist) for all `total_queries` rows on rank dst, (None, None) elsewhere.
     """
     local_fn = local_fn or _default_local_fn
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    lo, hi = shard_bounds(total_queries, world, rank)
-    assert y_shard.shape[0] == hi - lo, "y_shard does not match shard_bounds"
     idx, d = local_fn(x, y_shard)
-    rec = pack_records(idx, d)
-    # ragged shards: pad to the largest shard so every rank sends the same count
-    max_rows = shard_bounds(total_queries, world, 0)[1]
-    if rec.shape[0] < max_rows:
-        pad = torch.zeros((max_rows - rec.shape[0], 4), dtype=rec.dtype, device=rec.device)
-        rec = torch.cat([rec, pad], dim=0)
-    if rank == dst:
-        bufs = [torch.empty_like(rec) for _ in range(world)]
-        dist.gather(rec, gather_list=bufs, dst=dst, group=group)
-        parts = []
-        for r in range(world):
-            rlo, rhi = shard_bounds(total_queries, world, r)
-            parts.append(bufs[r][: rhi - rlo])
-        return unpack_records(torch.cat(parts, dim=0))
-    dist.gather(rec, gather_list=None, dst=dst, group=group)
-    return None, None
+    rec = gather_rows(pack_records(idx, d), total_queries, group, dst)
+    return unpack_records(rec) if rec is not None else (None, None)
+
+
+def nn_cascading_hash_sharded(x, y_shard, hash_dict, total_queries, g=2, group=None, dst=0, local_fn=None):
+    """Cascade-hash 2-NN with the queries sharded like `nn_bruteforcel1k2_sharded`: database,
+    hyperplanes (and therefore codes and bucket tables, rebuilt identically on every rank) are
+    replicated, each rank probes and refines its own query rows, one gather of 16-byte records
+    (the float32 distances travel bit-cast in the int32 record).
+
+    local_fn     (x, y, hash_dict, g) -> (idx int64 [n,2], dist float32 [n,2]); defaults to
+                 spectavi_amd.device.cascade.
+    Returns (idx int64 [N,2] with -1 = no neighbour, dist float32 [N,2]) on rank dst."""
+    if local_fn is None:
+        from spectavi_amd import device
+        local_fn = lambda a, b, d, gg: device.cascade(a, b, d, g=gg)[:2]  # noqa: E731
+    idx, d = local_fn(x, y_shard, hash_dict, g)
+    rec = gather_rows(pack_records(idx, d.contiguous().view(torch.int32)), total_queries, group, dst)
+    if rec is None:
+        return None, None
+    i, di = unpack_records(rec)
+    return i, di.view(torch.float32)
+
+
+def dlt_sharded(P0, P1, x_shard, xp_shard, total_points, want_error=False, group=None, dst=0, local_fn=None):
+    """Two-view triangulation (or its reprojection error) with the correspondences sharded over
+    the ranks; cameras replicated; one gather of 32 (8) bytes per point.
+
+    local_fn     (P0, P1, x, xp) -> float64 [n,4] (or [n,1]); defaults to
+                 spectavi_amd.device.dlt_triangulate / dlt_reprojection_error.
+    Returns float64 [total_points, 4] (or [total_points, 1]) on rank dst, None elsewhere."""
+    if local_fn is None:
+        from spectavi_amd import device
+        local_fn = device.dlt_reprojection_error if want_error else device.dlt_triangulate
+    out = local_fn(P0, P1, x_shard, xp_shard)
+    if out.dim() == 1:
+        out = out[:, None]
+    return gather_rows(out, total_points, group, dst)

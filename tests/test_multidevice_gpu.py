@@ -85,3 +85,46 @@ def test_concurrent_callers(oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_distributed_wrappers_single_rank_rccl(oracle):
+    """spectavi_amd.sharded with its default (HIP) local functions and an RCCL process group of
+    one rank on the box's GPU: the shard / pack / gather / unpack path on device tensors.  (Two
+    and more ranks run the same code; the gather itself is covered with gloo on CPU.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from spectavi_amd import sharded
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(5)
+        x = rng.integers(0, 256, (700, 128), dtype=np.uint8)
+        y = rng.integers(0, 256, (333, 128), dtype=np.uint8)
+        idx, d = sharded.nn_bruteforcel1k2_sharded(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), 333)
+        oi, od = oracle.nn_bruteforcel1k2(x, y)
+        assert np.array_equal(idx.cpu().numpy().view(np.uint64), oi) and np.array_equal(d.cpu().numpy(), od)
+
+        xf, yf = x.astype(np.float32) - 128, y.astype(np.float32) - 128
+        hd = rng.standard_normal((2, 128, 7)).astype(np.float32)
+        ci, cd = sharded.nn_cascading_hash_sharded(torch.from_numpy(xf).to(dev), torch.from_numpy(yf).to(dev),
+                                                   torch.from_numpy(hd).to(dev), 333, g=2)
+        wi, wd, _, _ = oracle.nn_cascading_hash(xf, yf, 7, 2, 2, hd)
+        assert np.array_equal(ci.cpu().numpy().view(np.uint64), wi) and np.array_equal(cd.cpu().numpy(), wd)
+
+        P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+        Xw = rng.standard_normal((501, 4))
+        px, pxp = torch.from_numpy(Xw @ P0.T).to(dev), torch.from_numpy(Xw @ P1.T).to(dev)
+        X = sharded.dlt_sharded(P0, P1, px, pxp, 501)
+        E = sharded.dlt_sharded(P0, P1, px, pxp, 501, want_error=True)
+        assert np.max(np.abs(X.cpu().numpy() - oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
+        assert E.shape == (501, 1) and float(E.max()) < 1e-6
+    finally:
+        dist.destroy_process_group()

@@ -73,3 +73,57 @@ def test_sharded_gather_world2_gloo(tmp_path):
         out = tmp_path / ("res%d.txt" % nq)
         mp.spawn(_worker, args=(2, _free_port(), nq, str(out)), nprocs=2, join=True)
         assert out.read_text() == "ok"
+
+
+def _worker_cascade_dlt(rank, world, port, nq, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from spectavi_amd.sharded import nn_cascading_hash_sharded, dlt_sharded, shard_bounds
+    rng = np.random.default_rng(23)
+    x = (rng.integers(0, 256, (400, 32)).astype(np.float32) - 128)
+    y = (rng.integers(0, 256, (nq, 32)).astype(np.float32) - 128)
+    hd = rng.standard_normal((3, 32, 6)).astype(np.float32)
+    lo, hi = shard_bounds(nq, world, rank)
+
+    def cascade_fn(xt, yt, dt, g):
+        idx, d, _, _ = o.nn_cascading_hash(xt.numpy(), yt.numpy(), dt.shape[2], dt.shape[0], g, dt.numpy())
+        return torch.from_numpy(idx.view(np.int64)), torch.from_numpy(d)
+
+    idx, d = nn_cascading_hash_sharded(torch.from_numpy(x), torch.from_numpy(y[lo:hi]), torch.from_numpy(hd), nq,
+                                       g=2, local_fn=cascade_fn)
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((nq, 4))
+    px, pxp = Xw @ P0.T, Xw @ P1.T
+
+    def tri_fn(a, b, c, e):
+        return torch.from_numpy(o.dlt_triangulate(a, b, c.numpy(), e.numpy()))
+
+    def err_fn(a, b, c, e):
+        return torch.from_numpy(o.dlt_reprojection_error(a, b, c.numpy(), e.numpy()))
+
+    X = dlt_sharded(P0, P1, torch.from_numpy(px[lo:hi]), torch.from_numpy(pxp[lo:hi]), nq, local_fn=tri_fn)
+    E = dlt_sharded(P0, P1, torch.from_numpy(px[lo:hi]), torch.from_numpy(pxp[lo:hi]), nq, want_error=True,
+                    local_fn=err_fn)
+    if rank == 0:
+        wi, wd, _, _ = o.nn_cascading_hash(x, y, 6, 3, 2, hd)
+        ok = np.array_equal(idx.numpy().view(np.uint64), wi) and np.array_equal(d.numpy(), wd)
+        ok = ok and np.array_equal(X.numpy(), o.dlt_triangulate(P0, P1, px, pxp))
+        ok = ok and np.array_equal(E.numpy().reshape(-1), o.dlt_reprojection_error(P0, P1, px, pxp).reshape(-1))
+        ok = ok and X.shape == (nq, 4) and E.shape == (nq, 1)
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    else:
+        assert idx is None and d is None and X is None and E is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_cascade_and_dlt_world2_gloo(tmp_path):
+    """Row (e) for the other two paths: cascade queries and DLT correspondences sharded over
+    two ranks, results gathered on rank 0 and compared with the unsharded oracle."""
+    for nq in (77, 40):
+        out = tmp_path / ("cd%d.txt" % nq)
+        mp.spawn(_worker_cascade_dlt, args=(2, _free_port(), nq, str(out)), nprocs=2, join=True)
+        assert out.read_text() == "ok"
