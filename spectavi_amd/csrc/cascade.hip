@@ -226,8 +226,9 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
             ranks[(size_t)j * nrows + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
         }
         if (IS_QUERY) {
-          // g smallest (|proj|, bit) pairs: sorted insertion, bits visited in ascending
-          // order so a strict < keeps the lower bit on equal magnitude
+          // g smallest (|proj|, bit) pairs, lexicographic like the reference's max-heap of
+          // pairs (src/CascadingHashNn.h:153-159): sorted insertion with the bit as tie-break,
+          // which matters for an entry displaced down the list past an equal magnitude
           float best[GMAX];
           int bbit[GMAX];
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
             int vb = b;
 #pragma unroll
             for (int q = 0; q < GMAX; ++q) {
-              const bool lt = q < g && v < best[q];
+              const bool lt = q < g && (v < best[q] || (v == best[q] && vb < bbit[q]));
               const float tv = best[q];
               const int tb = bbit[q];
               best[q] = lt ? v : tv;

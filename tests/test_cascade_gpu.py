@@ -39,6 +39,28 @@ def test_matches_oracle(oracle, m_rows, n_rows, dim, m, n, g):
     assert np.array_equal(idx, oidx)
 
 
+@pytest.mark.parametrize("m_rows,n_rows,dim,m,n,g,span", [
+    (2, 1350, 128, 6, 3, 4, 20), (300, 900, 64, 8, 2, 5, 2), (1000, 500, 32, 11, 3, 3, 20), (64, 64, 16, 4, 1, 2, 2),
+])
+def test_tied_projection_magnitudes(oracle, m_rows, n_rows, dim, m, n, g, span):
+    """Integer hyperplanes on small-integer data make |projection| ties and exact zeros common
+    (plus all-zero rows, whose projections all tie at +0): the g probe bits must be the g
+    smallest (|proj|, bit) PAIRS, lower bit first on equal magnitude, as the reference's heap of
+    pairs keeps them (src/CascadingHashNn.h:153-159) -- found by tools/fuzz_gpu.py."""
+    from spectavi_amd import feature
+    rng = np.random.default_rng([m_rows, n_rows, dim, m])
+    x = rng.integers(-span, span, (m_rows, dim)).astype(np.float32)
+    y = rng.integers(-span, span, (n_rows, dim)).astype(np.float32)
+    y[::17] = 0.0
+    x[::5] = 0.0
+    d = np.round(rng.standard_normal((n, dim, m))).astype(np.float32)
+    idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(x, y, m, n, g, d)
+    assert np.array_equal(ncand, oncand)
+    assert np.array_equal(dist, odist)
+    assert np.array_equal(idx, oidx)
+
+
 def test_reference_symbol_and_fallback(oracle):
     """nn_cascading_hash (NdArray path, library-drawn hyperplanes from a fixed seed) and the
     m<4 brute-force fallback of the front-end (reference spectavi/feature.py:364-371)."""
