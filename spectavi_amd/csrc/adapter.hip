@@ -231,6 +231,10 @@ int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigne
                   void *d_ws, size_t ws_bytes, hipStream_t stream) {
   if (rows < 0 || dim <= 0) return set_error(SPV_ERR_INVALID, "bad shape");
   if (rows == 0) return SPV_OK;
+  // numpy sums a single contiguous column pairwise, not row by row: that order is not
+  // reproduced here, so the one-column case is refused rather than answered differently
+  if (dim == 1 && rows > 1)
+    return set_error(SPV_ERR_INVALID, "normalisation of a single-column table is not supported (dim=1)");
   if (!d_x || (!d_out_f32 && !d_out_u8)) return set_error(SPV_ERR_INVALID, "null device pointer");
   if (!d_ws || ws_bytes < normalize_workspace_bytes(dim)) return set_error(SPV_ERR_INVALID, "workspace too small");
   float *stats = static_cast<float *>(d_ws);

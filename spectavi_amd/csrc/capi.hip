@@ -451,6 +451,8 @@ int host_sift_split(const float *table, int rows, float *geom, uint8_t *desc) {
 int host_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8) {
   if (rows < 0 || dim <= 0) return set_error(SPV_ERR_INVALID, "bad shape");
   if (rows == 0) return SPV_OK;
+  if (dim == 1 && rows > 1)
+    return set_error(SPV_ERR_INVALID, "normalisation of a single-column table is not supported (dim=1)");
   if (!x || (!out_f32 && !out_u8)) return set_error(SPV_ERR_INVALID, "null pointer");
   SPV_TRY(ensure_device());
   const int dim16 = (dim + 15) / 16 * 16;

@@ -257,7 +257,8 @@ _spv_normalize.argtypes = [ndpointer(ct.c_float, flags="C_CONTIGUOUS"), ct.c_int
 def normalize_to_ubyte_and_multiple_16_dim_gpu(x, want_ubyte=False):
     """`normalize_to_ubyte_and_multiple_16_dim(x)` for a float32 `x`, computed on the GPU and
     bit-identical to the numpy version; with `want_ubyte` also returns the
-    `(out + 128).astype('uint8')` image that `nn_bruteforcel1k2` takes."""
+    `(out + 128).astype('uint8')` image that `nn_bruteforcel1k2` takes.  A single-column
+    table (which numpy sums pairwise instead of row by row) is refused with SpectaviError."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, dim = x.shape
     dim16 = int(np.ceil(dim / 16.) * 16)

@@ -70,3 +70,14 @@ def test_normalize_bit_identical_to_numpy(golden, rows, dim, seed):
     assert got.dtype == np.float32 and got.shape == want.shape
     assert np.array_equal(got, want)
     assert np.array_equal(u8, (want + 128).astype('uint8'))
+
+
+def test_normalize_single_column_is_refused():
+    """numpy reduces one contiguous column pairwise, not row by row; the device path refuses
+    that shape instead of returning a differently rounded mean."""
+    import spectavi_amd
+    from spectavi_amd import feature
+    with pytest.raises(spectavi_amd.SpectaviError):
+        feature.normalize_to_ubyte_and_multiple_16_dim_gpu(np.arange(100, dtype=np.float32)[:, None])
+    one = feature.normalize_to_ubyte_and_multiple_16_dim_gpu(np.array([[3.0, 5.0]], np.float32))  # one row is fine
+    assert one.shape == (1, 16)

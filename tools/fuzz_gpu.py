@@ -112,15 +112,111 @@ def fuzz_dlt(seed, budget, only_case=None):
     return n
 
 
+def fuzz_ratio(seed, budget, only_case=None):
+    t0, n = time.time(), 0 if only_case is None else only_case
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, 3, n])
+        yrows = int(rng.choice([1, 2, 255, 256, 257, rng.integers(3, 5000), rng.integers(5000, 300000)]))
+        idx = rng.integers(0, 1 << 20, (yrows, 2)).astype(np.uint64)
+        is_float = bool(rng.integers(0, 2))
+        d0 = rng.integers(0, int(rng.choice([2, 50, 32641])), yrows)
+        d1 = d0 + rng.integers(0, int(rng.choice([1, 3, 20000])), yrows)
+        dist = np.stack([d0, d1], axis=1)
+        none = rng.random(yrows) < 0.05                 # no neighbour at all / only one
+        one = rng.random(yrows) < 0.05
+        idx[none] = np.iinfo(np.uint64).max
+        idx[one, 1] = np.iinfo(np.uint64).max
+        if is_float:
+            dist = dist.astype(np.float32)
+            dist[none] = 2147483648.0
+            dist[one, 1] = 2147483648.0
+        else:
+            dist = dist.astype(np.int32)
+            dist[none] = np.iinfo(np.int32).max
+            dist[one, 1] = np.iinfo(np.int32).max
+        ratio = float(rng.choice([0.0, 1.0, 1.25, 1.75, 3.0, 1e9]))
+        got = feature.ratio_test_matches(idx, dist, ratio)
+        want = o.ratio_test_matches(idx, dist, ratio)
+        if not np.array_equal(got, want):
+            raise SystemExit("RATIO MISMATCH case=%d yrows=%d float=%d ratio=%g got %d want %d rows" %
+                             (n, yrows, is_float, ratio, len(got), len(want)))
+        n += 1
+        if only_case is not None:
+            break
+    return n
+
+
+def fuzz_score(seed, budget, only_case=None):
+    t0, n = time.time(), 0 if only_case is None else only_case
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, 4, n])
+        npt = int(rng.choice([1, 63, 64, 65, 256, 257, rng.integers(2, 3000)]))
+        nhyp = int(rng.choice([1, 2, 4, rng.integers(5, 200)]))
+        P0 = np.hstack([np.eye(3), np.zeros((3, 1))]) if rng.random() < 0.5 else rng.standard_normal((3, 4))
+        R, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        t = rng.standard_normal((3, 1))
+        Ptrue = np.hstack([R, t]) if rng.random() < 0.7 else rng.standard_normal((3, 4))
+        Xw = rng.standard_normal((npt, 4))
+        Xw[:, 2] += 4.0
+        Xw[:, 3] = 1.0
+        x, xp = Xw @ P0.T, Xw @ Ptrue.T
+        x[:, :2] += 1e-3 * rng.standard_normal((npt, 2))
+        P1s = rng.standard_normal((nhyp, 3, 4))
+        P1s[0] = Ptrue
+        if nhyp > 1:
+            P1s[1] = np.hstack([R, -t])                 # behind-the-camera twin
+        thr = float(rng.choice([1e-4, 1e-2, 0.5, 1e3]))
+        c, mk = mvg.dlt_score_hypotheses(P0, P1s, x, xp, thr, return_mask=True)
+        oc, omk = o.dlt_score_hypotheses(P0, P1s, x, xp, thr)
+        if not (np.array_equal(c, oc) and np.array_equal(np.asarray(mk, bool), omk)):
+            raise SystemExit("SCORE MISMATCH case=%d npt=%d nhyp=%d thr=%g counts differ at %s" %
+                             (n, npt, nhyp, thr, np.flatnonzero(c != oc)[:5]))
+        n += 1
+        if only_case is not None:
+            break
+    return n
+
+
+def fuzz_normalize(seed, budget, only_case=None):
+    t0, n = time.time(), 0 if only_case is None else only_case
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, 5, n])
+        rows = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 511, 512, 513, 1023, 1025, rng.integers(2, 40000)]))
+        dim = int(rng.choice([2, 4, 15, 16, 17, 128, 132, 144, rng.integers(2, 300)]))   # dim 1 is refused
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            x = (rng.standard_normal((rows, dim)) * rng.uniform(0.1, 100, (1, dim)) + rng.uniform(-50, 50, (1, dim)))
+        elif kind == 1:
+            x = rng.integers(0, 256, (rows, dim)).astype(np.float64)       # SIFT-like integer values
+        else:
+            x = rng.standard_normal((rows, dim)) * 1e4 + 1e6               # large offsets: rounding in the chain
+        x = x.astype(np.float32)
+        if rows > 1:
+            x[0, 0] += 1.0                               # keep every column non-constant where possible
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = feature.normalize_to_ubyte_and_multiple_16_dim(x)
+        got, u8 = feature.normalize_to_ubyte_and_multiple_16_dim_gpu(x, want_ubyte=True)
+        ok = got.shape == want.shape and np.array_equal(got, want, equal_nan=True)
+        if ok and not np.isnan(want).any():
+            ok = np.array_equal(u8, (want + 128).astype('uint8'))
+        if not ok:
+            raise SystemExit("NORMALIZE MISMATCH case=%d rows=%d dim=%d kind=%d" % (n, rows, dim, kind))
+        n += 1
+        if only_case is not None:
+            break
+    return n
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0, help="budget per path")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma list of l1k2,cascade,dlt")
+    ap.add_argument("--only", default="", help="comma list of l1k2,cascade,dlt,ratio,score,normalize")
     ap.add_argument("--case", type=int, default=None, help="re-run one case number of the --only path")
     a = ap.parse_args()
     want = set(filter(None, a.only.split(",")))
-    for name, fn in (("l1k2", fuzz_l1k2), ("cascade", fuzz_cascade), ("dlt", fuzz_dlt)):
+    for name, fn in (("l1k2", fuzz_l1k2), ("cascade", fuzz_cascade), ("dlt", fuzz_dlt), ("ratio", fuzz_ratio),
+                     ("score", fuzz_score), ("normalize", fuzz_normalize)):
         if want and name not in want:
             continue
         cases = fn(a.seed, a.seconds, a.case)
