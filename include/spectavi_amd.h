@@ -34,6 +34,7 @@ extern "C" {
 #define SPV_ERR_INVALID 1 /* argument rejected (dim % 16, m > 31, k != 2, NULL ...) */
 #define SPV_ERR_HIP 2     /* HIP runtime / no device / launch failure */
 #define SPV_ERR_NOMEM 3   /* host or device allocation failed */
+#define SPV_ERR_INTERNAL 4 /* a C++ exception was caught at the boundary (never propagated) */
 
 /* Status of the last call made by this thread through any entry point below
  * (the void reference-compatible symbols report errors only this way). */

@@ -44,7 +44,7 @@ def _preload_torch_hip_runtime():
 _preload_torch_hip_runtime()
 clib = ct.cdll.LoadLibrary(lib_path)
 
-SPV_OK, SPV_ERR_INVALID, SPV_ERR_HIP, SPV_ERR_NOMEM = 0, 1, 2, 3
+SPV_OK, SPV_ERR_INVALID, SPV_ERR_HIP, SPV_ERR_NOMEM, SPV_ERR_INTERNAL = 0, 1, 2, 3, 4
 
 clib.spv_last_status.restype = ct.c_int
 clib.spv_last_status.argtypes = []

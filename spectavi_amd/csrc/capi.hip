@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
 #include <map>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -45,6 +47,22 @@ int set_error(int status, const char *fmt, ...) {
 void clear_error() {
   g_status = SPV_OK;
   g_message[0] = '\0';
+}
+
+// No C++ exception may cross the extern "C" boundary (the reference's own symbols let them
+// escape into libffi and abort the process, src/BruteForceNnL1K2.h:75,79): every entry point
+// runs its body through this.
+template <typename Fn>
+static int guard(Fn fn) {
+  try {
+    return fn();
+  } catch (const std::bad_alloc &) {
+    return set_error(SPV_ERR_NOMEM, "host allocation failed");
+  } catch (const std::exception &e) {
+    return set_error(SPV_ERR_INTERNAL, "unexpected C++ exception: %s", e.what());
+  } catch (...) {
+    return set_error(SPV_ERR_INTERNAL, "unexpected C++ exception");
+  }
 }
 
 // ---- optional kernel timing ----------------------------------------------------------
@@ -139,8 +157,11 @@ static int run_sharded(long long total, Fn fn) {
     const long long lo = r * base + std::min<long long>(r, extra);
     const long long hi = lo + base + (r < extra ? 1 : 0);
     threads.emplace_back([&, r, lo, hi] {
-      status[r] = fn(devs[r], lo, hi);
-      if (status[r] != SPV_OK) message[r] = g_message;
+      status[r] = guard([&] {
+        const int st = fn(devs[r], lo, hi);
+        if (st != SPV_OK) message[r] = g_message;
+        return st;
+      });
     });
   }
   for (auto &t : threads) t.join();
@@ -595,10 +616,12 @@ void nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows,
     set_error(SPV_ERR_INVALID, "negative row count");
     return;
   }
-  if (alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)) != SPV_OK) return;
-  if (alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(int)) != SPV_OK) return;
-  host_l1k2(x, y, xrows, yrows, dim, static_cast<uint64_t *>(outidx->m_data),
-            static_cast<int32_t *>(outdist->m_data));
+  (void)guard([&] {
+    SPV_TRY(alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)));
+    SPV_TRY(alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(int)));
+    return host_l1k2(x, y, xrows, yrows, dim, static_cast<uint64_t *>(outidx->m_data),
+                     static_cast<int32_t *>(outdist->m_data));
+  });
 }
 
 void nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int k,
@@ -609,53 +632,53 @@ void nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int
     set_error(SPV_ERR_INVALID, "k=%d: only k=2 is defined (reference writes exactly two columns)", k);
     return;
   }
-  if (check_cascade_args(xrows, yrows, dim, hash_bit_rate, num_hash_tables,
-                         num_candidate_neighbours) != SPV_OK)
-    return;
-  if (alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)) != SPV_OK) return;
-  if (alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(float)) != SPV_OK) return;
-  uint32_t seed;
-  {
-    std::lock_guard<std::mutex> lk(g_cfg_mutex);
-    const char *e = getenv("SPECTAVI_HASH_SEED");
-    if (g_seed_fixed)
-      seed = g_seed;
-    else if (e && *e)
-      seed = (uint32_t)strtoul(e, nullptr, 0);
-    else
-      seed = std::random_device{}();  // as reference src/CascadingHashNn.h:87-88
-  }
-  std::vector<float> dict((size_t)num_hash_tables * dim * hash_bit_rate);
-  fill_hash_dict(seed, dim, hash_bit_rate, num_hash_tables, dict.data());
-  host_cascade(x, y, xrows, yrows, dim, hash_bit_rate, num_hash_tables, num_candidate_neighbours,
-               dict.data(), static_cast<uint64_t *>(outidx->m_data),
-               static_cast<float *>(outdist->m_data), nullptr);
+  (void)guard([&] {
+    SPV_TRY(check_cascade_args(xrows, yrows, dim, hash_bit_rate, num_hash_tables, num_candidate_neighbours));
+    SPV_TRY(alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)));
+    SPV_TRY(alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(float)));
+    uint32_t seed;
+    {
+      std::lock_guard<std::mutex> lk(g_cfg_mutex);
+      const char *e = getenv("SPECTAVI_HASH_SEED");
+      if (g_seed_fixed)
+        seed = g_seed;
+      else if (e && *e)
+        seed = (uint32_t)strtoul(e, nullptr, 0);
+      else
+        seed = std::random_device{}();  // as reference src/CascadingHashNn.h:87-88
+    }
+    std::vector<float> dict((size_t)num_hash_tables * dim * hash_bit_rate);
+    fill_hash_dict(seed, dim, hash_bit_rate, num_hash_tables, dict.data());
+    return host_cascade(x, y, xrows, yrows, dim, hash_bit_rate, num_hash_tables, num_candidate_neighbours,
+                        dict.data(), static_cast<uint64_t *>(outidx->m_data),
+                        static_cast<float *>(outdist->m_data), nullptr);
+  });
 }
 
 void dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                      const double *xp, double *dst) {
   clear_error();
-  host_dlt(P0, P1, npt, x, xp, dst, false);
+  (void)guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, false); });
 }
 
 void dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                             const double *xp, double *dst) {
   clear_error();
-  host_dlt(P0, P1, npt, x, xp, dst, true);
+  (void)guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, true); });
 }
 
 // ---- host-pointer status variants ---------------------------------------------------
 int spv_nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
                           uint64_t *idx, int32_t *dist) {
   clear_error();
-  return host_l1k2(x, y, xrows, yrows, dim, idx, dist);
+  return guard([&] { return host_l1k2(x, y, xrows, yrows, dim, idx, dist); });
 }
 
 int spv_nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int m,
                           int n, int g, const float *dict, uint64_t *idx, float *dist,
                           int32_t *ncand) {
   clear_error();
-  return host_cascade(x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand);
+  return guard([&] { return host_cascade(x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand); });
 }
 
 int spv_generate_hash_dict(uint32_t seed, int dim, int m, int n, float *dict) {
@@ -674,65 +697,65 @@ void spv_set_hash_seed(uint32_t seed, int use_fixed) {
 int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                         const double *xp, double *dst) {
   clear_error();
-  return host_dlt(P0, P1, npt, x, xp, dst, false);
+  return guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, false); });
 }
 int spv_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8) {
   clear_error();
-  return host_normalize(x, rows, dim, out_f32, out_u8);
+  return guard([&] { return host_normalize(x, rows, dim, out_f32, out_u8); });
 }
 size_t spv_normalize_workspace_bytes(int dim) { return dim <= 0 ? 0 : normalize_workspace_bytes(dim); }
 int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, uint8_t *d_out_u8,
                          void *d_ws, size_t ws_bytes, void *stream) {
   clear_error();
-  return normalize_run(d_x, rows, dim, d_out_f32, d_out_u8, d_ws, ws_bytes, static_cast<hipStream_t>(stream));
+  return guard([&] { return normalize_run(d_x, rows, dim, d_out_f32, d_out_u8, d_ws, ws_bytes, static_cast<hipStream_t>(stream)); });
 }
 int spv_sift_split(const float *table, int rows, float *geom, uint8_t *desc) {
   clear_error();
-  return host_sift_split(table, rows, geom, desc);
+  return guard([&] { return host_sift_split(table, rows, geom, desc); });
 }
 int spv_sift_split_device(const float *d_table, int rows, float *d_geom, uint8_t *d_desc,
                           void *stream) {
   clear_error();
-  return sift_split_run(d_table, rows, d_geom, d_desc, static_cast<hipStream_t>(stream));
+  return guard([&] { return sift_split_run(d_table, rows, d_geom, d_desc, static_cast<hipStream_t>(stream)); });
 }
 int spv_gather_match_coords_device(const float *d_geom_x, const float *d_geom_y,
                                    const int32_t *d_matches, const int32_t *d_count, int capacity,
                                    double *d_x0, double *d_x1, void *stream) {
   clear_error();
-  return gather_match_coords_run(d_geom_x, d_geom_y, d_matches, d_count, capacity, d_x0, d_x1,
-                                 static_cast<hipStream_t>(stream));
+  return guard([&] { return gather_match_coords_run(d_geom_x, d_geom_y, d_matches, d_count, capacity, d_x0, d_x1,
+                                 static_cast<hipStream_t>(stream)); });
 }
 int spv_ratio_test(const uint64_t *idx, const void *dist, int dist_is_float, int yrows,
                    double min_ratio, int32_t *matches, int32_t *count) {
   clear_error();
-  return host_ratio(idx, dist, dist_is_float, yrows, min_ratio, matches, count);
+  return guard([&] { return host_ratio(idx, dist, dist_is_float, yrows, min_ratio, matches, count); });
 }
 size_t spv_ratio_test_workspace_bytes(int yrows) { return yrows < 0 ? 0 : ratio_workspace_bytes(yrows); }
 int spv_ratio_test_device(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int yrows,
                           double min_ratio, int32_t *d_matches, int32_t *d_count, void *d_ws,
                           size_t ws_bytes, void *stream) {
   clear_error();
-  return ratio_run(d_idx, d_dist, dist_is_float, yrows, min_ratio, d_matches, d_count, d_ws, ws_bytes,
-                   static_cast<hipStream_t>(stream));
+  return guard([&] { return ratio_run(d_idx, d_dist, dist_is_float, yrows, min_ratio, d_matches, d_count, d_ws, ws_bytes,
+                   static_cast<hipStream_t>(stream)); });
 }
 int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
                              const double *x, const double *xp, double max_error,
                              int32_t *counts, uint8_t *mask) {
   clear_error();
-  return host_dlt_score(P0, P1s, nhyp, npt, x, xp, max_error, counts, mask);
+  return guard([&] { return host_dlt_score(P0, P1s, nhyp, npt, x, xp, max_error, counts, mask); });
 }
 int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,
                                     long long npt, const double *d_x, const double *d_xp,
                                     double max_error, int32_t *d_counts, uint8_t *d_mask,
                                     void *stream) {
   clear_error();
-  return dlt_score_run(P0, d_P1s, nhyp, npt, d_x, d_xp, max_error, d_counts, d_mask,
-                       static_cast<hipStream_t>(stream));
+  return guard([&] { return dlt_score_run(P0, d_P1s, nhyp, npt, d_x, d_xp, max_error, d_counts, d_mask,
+                       static_cast<hipStream_t>(stream)); });
 }
 int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                                const double *xp, double *dst) {
   clear_error();
-  return host_dlt(P0, P1, npt, x, xp, dst, true);
+  return guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, true); });
 }
 
 // ---- device-pointer variants --------------------------------------------------------
@@ -745,8 +768,8 @@ size_t spv_l1k2_workspace_bytes(int xrows, int yrows, int dim) {
 int spv_l1k2_device(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int dim,
                     uint64_t *d_idx, int32_t *d_dist, void *d_ws, size_t ws_bytes, void *stream) {
   clear_error();
-  return l1k2_run(d_x, d_y, xrows, yrows, dim, d_idx, d_dist, d_ws, ws_bytes,
-                  static_cast<hipStream_t>(stream));
+  return guard([&] { return l1k2_run(d_x, d_y, xrows, yrows, dim, d_idx, d_dist, d_ws, ws_bytes,
+                  static_cast<hipStream_t>(stream)); });
 }
 
 size_t spv_cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g) {
@@ -760,23 +783,25 @@ int spv_cascade_device(const float *d_x, const float *d_y, int xrows, int yrows,
                        int n, int g, const float *d_dict, uint64_t *d_idx, float *d_dist,
                        int32_t *d_ncand, void *d_ws, size_t ws_bytes, void *stream) {
   clear_error();
-  int s = check_cascade_args(xrows, yrows, dim, m, n, g);
-  if (s != SPV_OK) return s;
-  return cascade_run(d_x, d_y, xrows, yrows, dim, m, n, g, d_dict, d_idx, d_dist, d_ncand, d_ws,
-                     ws_bytes, static_cast<hipStream_t>(stream));
+  return guard([&] {
+    int s = check_cascade_args(xrows, yrows, dim, m, n, g);
+    if (s != SPV_OK) return s;
+    return cascade_run(d_x, d_y, xrows, yrows, dim, m, n, g, d_dict, d_idx, d_dist, d_ncand, d_ws,
+                       ws_bytes, static_cast<hipStream_t>(stream));
+  });
 }
 
 int spv_dlt_triangulate_device(const double *P0, const double *P1, long long npt,
                                const double *d_x, const double *d_xp, double *d_dst,
                                void *stream) {
   clear_error();
-  return dlt_run(P0, P1, npt, d_x, d_xp, d_dst, false, static_cast<hipStream_t>(stream));
+  return guard([&] { return dlt_run(P0, P1, npt, d_x, d_xp, d_dst, false, static_cast<hipStream_t>(stream)); });
 }
 int spv_dlt_reprojection_error_device(const double *P0, const double *P1, long long npt,
                                       const double *d_x, const double *d_xp, double *d_dst,
                                       void *stream) {
   clear_error();
-  return dlt_run(P0, P1, npt, d_x, d_xp, d_dst, true, static_cast<hipStream_t>(stream));
+  return guard([&] { return dlt_run(P0, P1, npt, d_x, d_xp, d_dst, true, static_cast<hipStream_t>(stream)); });
 }
 
 }  // extern "C"
