@@ -8,7 +8,8 @@
 // HBM and these kernels:
 //
 //   1 repack_dict     dict[n][dim][m] -> dictp[n][dim][MC], MC = roundup(m,4), zero padded
-//   2 project<false>  database rows: n*m random-hyperplane projections as a
+//   2 project<false>  database rows: n*m random-hyperplane projections (on the matrix cores
+//                     when n*m <= 64, project_mfma_kernel; else the VALU project_kernel) as a
 //                     dim-ordered fp32 FMA chain (the oracle runs the identical
 //                     chain, so sign bits match bit for bit), sign-packed codes
 //                     (bit b set iff proj >= 0, src/CascadingHashNn.h:102-111), the
@@ -258,6 +259,196 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
           if (r < nrows) masks[(size_t)j * nrows + r] = mask;
         }
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 2b/3b. the same projections on the matrix cores (used when all n*m hyperplanes fit 64
+// columns, i.e. every default configuration).  The projection is the one GEMM-shaped step of
+// the path: P[rows][n*m] = X[rows][dim] * H[dim][n*m].  v_mfma_f32_16x16x4_f32 accumulates each
+// output element as a sequential fp32 FMA chain in k order -- checked against std::fmaf on
+// 64 000 outputs, tools/exp/mfma_order.hip: 100 % identical -- so the result is bit for bit the
+// chain the oracle and the VALU kernel above compute, at four times the FMA rate and without
+// the LDS broadcast traffic that bounds the VALU kernel.
+//
+// One wave owns 64 rows (waves are independent: no workgroup barriers).  Per 32-dim step
+// the wave's float4 loads (eight lanes cover one full 128-byte line of a row; prefetched one
+// step ahead; the uint8 image is packed from the same registers) are staged in a
+// wave-private LDS tile, from which lane
+// (r = lane % 16, q = lane / 16) reads A[row r of row-tile rt][k + q]; the hyperplane operand
+// B[k + q][column] comes straight from the repacked dictionary dictm[dim][16*CT] (L1/L2
+// resident).  4 x CT accumulator tiles of 16 x 16.  Afterwards the tiles are transposed
+// through LDS so that one lane holds one row's n*m projections and runs the same epilogue as
+// the VALU kernel: sign codes, the g least-confident bits, bucket histogram.
+// ---------------------------------------------------------------------------------
+__global__ void repack_dict_mfma_kernel(const float *__restrict__ dict, float *__restrict__ dictm, int n,
+                                        int dim, int m, int nc) {
+  const int total = dim * nc;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int c = e % nc, i = e / nc;  // column c = table * m + bit
+    const int tj = c / m, b = c % m;
+    dictm[e] = tj < n ? dict[((size_t)tj * dim + i) * m + b] : 0.f;
+  }
+}
+
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaChunk = 32;  // dims per step: 8 lanes x 16 B = one full 128-byte line per row
+
+template <int CT, bool IS_QUERY, int GMAX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 3 ? 3 : 2))) void project_mfma_kernel(
+    const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
+    const float *__restrict__ dictm,     // [dim][16*CT], column = table*m + bit, zero padded
+    uint32_t *__restrict__ codes, uint32_t *__restrict__ masks, uint8_t *__restrict__ u8img,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ ranks, uint32_t hbmask, int nb) {
+  constexpr int NC = 16 * CT;
+  constexpr int KS = kMfmaChunk / 4;   // MFMA k-steps per chunk
+  constexpr int NX = kMfmaChunk / 4;   // float4 loads per lane per chunk (64 rows x 32 dims / 64 lanes / 4)
+  constexpr int XS = kMfmaChunk + 1;   // floats per staged row (+1: spreads the rows over the banks)
+  constexpr int ES = NC + 1;           // floats per row of the transposed projections
+  constexpr int kWaveFloats = 64 * (ES > XS ? ES : XS);
+  __shared__ float lds[(kThreads / 64) * kWaveFloats];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *ws = lds + wv * kWaveFloats;
+  const long long row0 = ((long long)blockIdx.x * (kThreads / 64) + wv) * 64;
+  if (row0 >= nrows) return;  // whole wave past the end (nothing below synchronises across waves)
+  const int r16 = lane & 15, q4 = lane >> 4;
+
+  mfma_f4 acc[4][CT];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+  float4 px[NX];
+  // dims past the end of a row (dim % 32 == 16) are staged as zeros and multiply zero
+  // hyperplanes: fmaf(0, 0, acc) leaves every accumulator as it is
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = lane + 64 * j;  // (row of the tile, 4-dim part of the step): 8 lanes per row
+      const long long grow = min(row0 + (e >> 3), (long long)nrows - 1);
+      const int d0 = c0 + 4 * (e & 7);
+      px[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d0 < dim)  // read once: keep the rows out of the way of the hyperplanes in L1
+      {
+        const mfma_f4 t4 = __builtin_nontemporal_load(reinterpret_cast<const mfma_f4 *>(rows + (size_t)grow * dim + d0));
+        px[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+      }
+    }
+  };
+  // hyperplane operand of one k-step, fetched one k-step ahead of its use (L1 / L2 resident)
+  float bn[CT];
+  auto fetch_b = [&](int k0) {
+    const int k = k0 + q4;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bn[ct] = k < dim ? dictm[(size_t)k * NC + 16 * ct + r16] : 0.f;
+  };
+  prefetch(0);
+  fetch_b(0);
+  for (int c0 = 0; c0 < dim; c0 += kMfmaChunk) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = lane + 64 * j;
+      const int row = e >> 3, part = e & 7;
+      const float4 v = px[j];
+      float *dstp = ws + row * XS + 4 * part;
+      dstp[0] = v.x;
+      dstp[1] = v.y;
+      dstp[2] = v.z;
+      dstp[3] = v.w;
+      if (row0 + row < nrows && c0 + 4 * part < dim) {
+        const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
+        *reinterpret_cast<uint32_t *>(u8img + (size_t)(row0 + row) * dim + c0 + 4 * part) = pk;
+      }
+    }
+    if (c0 + kMfmaChunk < dim) prefetch(c0 + kMfmaChunk);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float bc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) bc[ct] = bn[ct];
+      fetch_b(c0 + 4 * (ks + 1));  // the next k-step (of the next chunk after the last one; zeros past dim)
+      float a[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) a[rt] = ws[(16 * rt + r16) * XS + 4 * ks + q4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bc[ct], acc[rt][ct], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // transpose: D tile element v of lane (r16, q4) is row 16*rt + 4*q4 + v, column 16*ct + r16
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ws[(16 * rt + 4 * q4 + v) * ES + 16 * ct + r16] = acc[rt][ct][v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const long long r = row0 + lane;
+  const float *mine = ws + lane * ES;
+  for (int j = 0; j < n; ++j) {
+    uint32_t code = 0;
+    float best[GMAX];
+    int bbit[GMAX];
+#pragma unroll
+    for (int q = 0; q < GMAX; ++q) {
+      best[q] = __builtin_inff();
+      bbit[q] = -1;
+    }
+    // eight projections per round: the LDS reads of a round are independent, so their latency
+    // is paid once per round instead of once per bit
+    for (int b0 = 0; b0 < m; b0 += 8) {
+      float p8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p8[i] = mine[min(j * m + b0 + i, NC)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = b0 + i;
+        const bool live = b < m;
+        const float p = p8[i];
+        code |= (live && p >= 0.f ? 1u : 0u) << (b & 31);
+        if (IS_QUERY) {
+          // g smallest (|proj|, bit) pairs, lexicographic (see the VALU kernel's epilogue);
+          // slots past m enter as +inf and are never inserted
+          float v = live ? fabsf(p) : __builtin_inff();
+          int vb = b;
+#pragma unroll
+          for (int q = 0; q < GMAX; ++q) {
+            const bool lt = q < g && (v < best[q] || (v == best[q] && vb < bbit[q]));
+            const float tv = best[q];
+            const int tb = bbit[q];
+            best[q] = lt ? v : tv;
+            bbit[q] = lt ? vb : tb;
+            v = lt ? tv : v;
+            vb = lt ? tb : vb;
+          }
+        }
+      }
+    }
+    if (r < nrows) {
+      codes[(size_t)j * nrows + r] = code;
+      if (!IS_QUERY && counts)
+        ranks[(size_t)j * nrows + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
+    }
+    if (IS_QUERY) {
+      uint32_t mask = 0;
+#pragma unroll
+      for (int q = 0; q < GMAX; ++q)
+        if (q < g && bbit[q] >= 0) mask |= 1u << bbit[q];
+      if (r < nrows) masks[(size_t)j * nrows + r] = mask;
     }
   }
 }
@@ -730,7 +921,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
 
 struct CascadeLayout {
   int mc, hb;
-  size_t off_dictp, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart,
+  size_t off_dictp, off_dictm, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart,
       off_order, off_ranks, off_segsum, total;
 };
 
@@ -746,6 +937,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
     return o;
   };
   L.off_dictp = take((size_t)n * dim * L.mc * sizeof(float));
+  L.off_dictm = take((size_t)dim * 64 * sizeof(float));  // MFMA layout, at most 64 columns
   L.off_ux = take((size_t)xrows * dim);
   L.off_uy = take((size_t)yrows * dim);
   L.off_xcodes = take((size_t)n * xrows * sizeof(uint32_t));
@@ -808,6 +1000,42 @@ void launch_project(int mc, int g, const float *rows, int nrows, int dim, int m,
 #undef SPV_LAUNCH_PROJECT
 }
 
+// Matrix-core projection: applies when the n*m hyperplanes fit 64 columns.
+inline bool project_mfma_applies(int m, int n) {
+  static const bool off = [] {
+    const char *e = getenv("SPECTAVI_CASCADE_MFMA");
+    return e && e[0] == '0';
+  }();
+  return !off && (long long)n * m <= 64;
+}
+
+template <bool IS_QUERY>
+void launch_project_mfma(int g, const float *rows, int nrows, int dim, int m, int n, const float *dictm,
+                         uint32_t *codes, uint32_t *masks, uint8_t *img, uint32_t *counts,
+                         uint32_t *ranks, uint32_t hbmask, int nb, hipStream_t stream) {
+  if (nrows <= 0) return;
+  const int ct = (n * m + 15) / 16;
+  const dim3 grid((nrows + kThreads - 1) / kThreads), block(kThreads);
+  constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
+#define SPV_LAUNCH_MFMA(CTV)                                                                         \
+  case CTV:                                                                                          \
+    if (g <= G1)                                                                                     \
+      hipLaunchKernelGGL((project_mfma_kernel<CTV, IS_QUERY, G1>), grid, block, 0, stream, rows,     \
+                         nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb);  \
+    else                                                                                             \
+      hipLaunchKernelGGL((project_mfma_kernel<CTV, IS_QUERY, G2>), grid, block, 0, stream, rows,     \
+                         nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb);  \
+    break;
+  switch (ct) {
+    SPV_LAUNCH_MFMA(1)
+    SPV_LAUNCH_MFMA(2)
+    SPV_LAUNCH_MFMA(3)
+    default:
+      SPV_LAUNCH_MFMA(4)
+  }
+#undef SPV_LAUNCH_MFMA
+}
+
 }  // namespace
 
 size_t cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g) {
@@ -841,12 +1069,23 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
   {
   ProfScope prof("cascade_project", stream);
-  hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
-                     m, L.mc);
-  launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, bstart, ranks, hbmask,
-                        nb, stream);
-  launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, nullptr, nullptr, hbmask,
-                       nb, stream);
+  if (project_mfma_applies(m, n)) {
+    float *dictm = reinterpret_cast<float *>(ws + L.off_dictm);
+    const int nc = (n * m + 15) / 16 * 16;
+    hipLaunchKernelGGL(repack_dict_mfma_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictm, n, dim,
+                       m, nc);
+    launch_project_mfma<false>(0, d_x, xrows, dim, m, n, dictm, xcodes, nullptr, ux, bstart, ranks, hbmask,
+                               nb, stream);
+    launch_project_mfma<true>(g, d_y, yrows, dim, m, n, dictm, ysign, ymask, uy, nullptr, nullptr, hbmask,
+                              nb, stream);
+  } else {
+    hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
+                       m, L.mc);
+    launch_project<false>(L.mc, 0, d_x, xrows, dim, m, n, dictp, xcodes, nullptr, ux, bstart, ranks, hbmask,
+                          nb, stream);
+    launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, nullptr, nullptr, hbmask,
+                         nb, stream);
+  }
   }
   SPV_HIP_CHECK(hipGetLastError());
 
