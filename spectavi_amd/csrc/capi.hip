@@ -139,6 +139,18 @@ static std::vector<int> device_list() {
 
 int ensure_device() { return use_device(device_list()[0]); }
 
+int device_cu_count() {
+  static std::atomic<int> cache[64];  // per device, 0 = not asked yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  int cus = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (cus <= 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1;
+    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+  }
+  return cus;
+}
+
 // Splits [0, total) into contiguous balanced shards, one per configured device, and runs
 // fn(device, lo, hi) on a host thread per shard (every row of the hot path is independent:
 // the reference parallelises the same loop with OpenMP, src/BruteForceNnL1K2.h:92).  Each

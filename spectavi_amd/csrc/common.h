@@ -28,6 +28,9 @@ void clear_error();
 // Selects the process-wide device for host-pointer entry points on this thread.
 int ensure_device();
 
+// Compute units of the calling thread's current device (cached per device; 256 on MI355X).
+int device_cu_count();
+
 // Brackets a kernel launch with hipEvents on `stream` while profiling is enabled.
 struct ProfScope {
   ProfScope(const char *name, hipStream_t stream);

@@ -22,8 +22,6 @@
 
 #include "common.h"
 
-#include <atomic>
-
 namespace spv {
 namespace {
 
@@ -397,14 +395,7 @@ int dlt_run(const double *P0, const double *P1, long long npt, const double *d_x
     cam.p1[i] = P1[i];
   }
   // persistent grid: at most 32 workgroups per CU, each lane strides over its points
-  static std::atomic<int> cu_count[64];  // per device, 0 = not asked yet
-  int dev = 0;
-  SPV_HIP_CHECK(hipGetDevice(&dev));
-  int cus = (dev >= 0 && dev < 64) ? cu_count[dev].load(std::memory_order_relaxed) : 0;
-  if (cus <= 0) {
-    SPV_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (dev >= 0 && dev < 64) cu_count[dev].store(cus, std::memory_order_relaxed);
-  }
+  const int cus = device_cu_count();
   const long long blocks = std::min<long long>((npt + kDltThreads - 1) / kDltThreads, (long long)std::max(cus, 1) * 32);
   ProfScope prof("dlt", stream);
   if (want_error)
