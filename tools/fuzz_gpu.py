@@ -99,6 +99,10 @@ def fuzz_dlt(seed, budget, only_case=None):
             x *= 1e6                                             # large homogeneous scale
         if kind == 5:
             x[: max(1, npt // 10)] = xp[: max(1, npt // 10)]    # inconsistent pairs
+        if rng.random() < 0.15:                                  # w = 0 / non-finite observations: inf and nan
+            x[rng.integers(0, npt), 2] = 0.0                     # must come out in the same places on both sides
+            xp[rng.integers(0, npt), 2] = 0.0
+            x[rng.integers(0, npt), 0] = np.inf if rng.random() < 0.5 else np.nan
         X = mvg.dlt_triangulate(P0, P1, x, xp)
         E = mvg.dlt_reprojection_error(P0, P1, x, xp)
         oX, oE = o.dlt_triangulate(P0, P1, x, xp), o.dlt_reprojection_error(P0, P1, x, xp)
