@@ -2,8 +2,8 @@
 many random shapes / parameters per path, for a time budget.  Prints one line per path and
 exits non-zero on the first mismatch (with the failing configuration).
 
-    python tools/fuzz_gpu.py --seconds 60 --seed 1
-    python tools/fuzz_gpu.py --only cascade --case 17 --seed 1     # re-run one reported case
+    python tests/fuzz_gpu.py --seconds 60 --seed 1
+    python tests/fuzz_gpu.py --only cascade --case 17 --seed 1     # re-run one reported case
 """
 import argparse
 import os

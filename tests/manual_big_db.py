@@ -1,6 +1,6 @@
 """One-off: L1 2-NN against a 20M-row database (2.56 GB, row offsets beyond 2^31 bytes)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from spectavi_amd import device as spv
 from oracle import oracle as o

@@ -46,7 +46,7 @@ def test_tied_projection_magnitudes(oracle, m_rows, n_rows, dim, m, n, g, span):
     """Integer hyperplanes on small-integer data make |projection| ties and exact zeros common
     (plus all-zero rows, whose projections all tie at +0): the g probe bits must be the g
     smallest (|proj|, bit) PAIRS, lower bit first on equal magnitude, as the reference's heap of
-    pairs keeps them (src/CascadingHashNn.h:153-159) -- found by tools/fuzz_gpu.py."""
+    pairs keeps them (src/CascadingHashNn.h:153-159) -- found by tests/fuzz_gpu.py."""
     from spectavi_amd import feature
     rng = np.random.default_rng([m_rows, n_rows, dim, m])
     x = rng.integers(-span, span, (m_rows, dim)).astype(np.float32)

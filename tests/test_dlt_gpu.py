@@ -66,8 +66,11 @@ def test_device_path_10m_properties():
     Xw = torch.randn((npt, 4), dtype=torch.float64, device="cuda", generator=g)
     Xw[:, 2] += 5.0
     Xw[:, 3] = 1.0
-    x = Xw @ torch.from_numpy(P0).cuda().T
-    xp = Xw @ torch.from_numpy(P1).cuda().T
+    def project(P):  # elementwise on purpose: no dependency on a BLAS library being loaded
+        Pt = torch.from_numpy(P).cuda()
+        return torch.stack([(Xw * Pt[r]).sum(1) for r in range(3)], dim=1).contiguous()
+
+    x, xp = project(P0), project(P1)
     X = device.dlt_triangulate(P0, P1, x, xp)
     err = device.dlt_reprojection_error(P0, P1, x, xp)
     torch.cuda.synchronize()
