@@ -167,10 +167,22 @@ def main():
     launches, tile_ms = spv.profile_read("l1k2_tile")
     _, merge_ms = spv.profile_read("l1k2_merge")
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
+    # the exchange step on its own ("report its time as a separate line"): K packs +
+    # gathers of the last result, outside the timed region
+    gather_s = 0.0
+    if world > 1:
+        fence()
+        g0 = time.perf_counter()
+        for _ in range(args.steps):
+            rec = pack_records(idx, d)
+            dist.gather(rec.cpu() if rehearse else rec, gather_list=gather_bufs, dst=0)
+        fence()
+        gather_s = time.perf_counter() - g0
+
+    t = torch.tensor([elapsed, gather_s], dtype=torch.float64, device=gdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, gather_s = float(t[0].item()), float(t[1].item())
 
     pairs_per_step = float(args.xrows) * args.yrows * world
     value = pairs_per_step * args.steps / elapsed
@@ -219,6 +231,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "verified_vs_oracle": verified,
         }
         if world > 1:
+            out["gather_ms_per_step"] = gather_s / args.steps * 1e3  # pack + RCCL gather alone, max over ranks
             # shard 0 of the gathered records must be rank 0's own result
             i0, d0 = gather_bufs[0][:, 0:2].to(dev), gather_bufs[0][:, 2:4].to(dev)
             out["gather_consistent"] = bool(torch.equal(i0, idx.to(torch.int32)) and torch.equal(d0, d))
