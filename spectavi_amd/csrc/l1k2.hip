@@ -140,7 +140,7 @@ __device__ __forceinline__ uint64_t widen_key(uint32_t k, uint32_t slice_base) {
 // Thread t of query block qb owns queries qb*256*Q + q*256 + t, q = 0..Q-1.
 // ---------------------------------------------------------------------------------
 template <int D4, int Q>
-__global__ __launch_bounds__(kThreads, 2) void l1k2_tile_kernel(
+__global__ __launch_bounds__(kThreads, (D4 <= 48 ? 3 : 2)) void l1k2_tile_kernel(
     const uint4 *__restrict__ x, const uint4 *__restrict__ y, int M, int N, int slice_rows,
     int S, uint64_t *__restrict__ part) {
   constexpr int V4 = D4 / 4;                                   // 16-byte vectors per row
