@@ -98,23 +98,24 @@ __device__ __forceinline__ void row_update(const uint32_t (&qreg)[Q][D4], const 
   }
 }
 
-// Half-row form for wide descriptors (dim 192 / 256): the row is consumed as two chunks of
-// H4 = D4/2 dwords so that only one chunk-sized buffer pair is live next to 2 x D4 query
-// registers (two queries per lane keep the LDS broadcast amortised).
-template <int D4, int Q, int HALF>
-__device__ __forceinline__ void half_accumulate(const uint32_t (&qreg)[Q][D4],
-                                                const uint4 (&xh)[D4 / 8], uint32_t (&acc)[Q]) {
-  constexpr int H4 = D4 / 2;
+// Chunked-row form for wide descriptors: the row is consumed as NCH chunks of CH4 = D4/NCH
+// dwords (two for dim 192, four for dim 256) so that only one chunk-sized buffer pair is live
+// next to the 2 x D4 query registers (two queries per lane keep the LDS broadcast amortised)
+// and the kernel keeps three waves per SIMD.
+template <int D4, int Q, int NCH, int C>
+__device__ __forceinline__ void chunk_accumulate(const uint32_t (&qreg)[Q][D4],
+                                                 const uint4 (&xc)[D4 / NCH / 4], uint32_t (&acc)[Q]) {
+  constexpr int CH4 = D4 / NCH;
 #pragma unroll
-  for (int c = 0; c < H4 / 4; ++c) {
+  for (int c = 0; c < CH4 / 4; ++c) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 0], xh[c].x, acc[q]);
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][C * CH4 + 4 * c + 0], xc[c].x, acc[q]);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 1], xh[c].y, acc[q]);
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][C * CH4 + 4 * c + 1], xc[c].y, acc[q]);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 2], xh[c].z, acc[q]);
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][C * CH4 + 4 * c + 2], xc[c].z, acc[q]);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][HALF * H4 + 4 * c + 3], xh[c].w, acc[q]);
+    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][C * CH4 + 4 * c + 3], xc[c].w, acc[q]);
   }
 }
 
@@ -140,7 +141,7 @@ __device__ __forceinline__ uint64_t widen_key(uint32_t k, uint32_t slice_base) {
 // Thread t of query block qb owns queries qb*256*Q + q*256 + t, q = 0..Q-1.
 // ---------------------------------------------------------------------------------
 template <int D4, int Q>
-__global__ __launch_bounds__(kThreads, (D4 <= 48 ? 3 : 2)) void l1k2_tile_kernel(
+__global__ __launch_bounds__(kThreads, 3) void l1k2_tile_kernel(
     const uint4 *__restrict__ x, const uint4 *__restrict__ y, int M, int N, int slice_rows,
     int S, uint64_t *__restrict__ part) {
   constexpr int V4 = D4 / 4;                                   // 16-byte vectors per row
@@ -211,19 +212,31 @@ __global__ __launch_bounds__(kThreads, (D4 <= 48 ? 3 : 2)) void l1k2_tile_kernel
     const uint32_t jbase = (uint32_t)(row0 - row_begin);
 
     if constexpr (D4 >= 48) {
-      // wide rows: two half-row chunks per row, the next chunk's LDS reads issued before
-      // the current chunk's SAD chain
-      constexpr int HV = V4 / 2;
-      uint4 xa[HV], xb[HV];
-      lds_row<HV>(xa, buf);
+      // wide rows: NCH chunks per row, the next chunk's LDS reads issued before the current
+      // chunk's SAD chain (xa / xb alternate; the last chunk prefetches the next row's first)
+      constexpr int NCH = D4 >= 64 ? 4 : 2;
+      constexpr int CV = V4 / NCH;
+      uint4 xa[CV], xb[CV];
+      lds_row<CV>(xa, buf);
       for (int r = 0; r < nrows; ++r) {
         uint32_t acc[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = jbase + r;
-        lds_row<HV>(xb, buf + r * V4 + HV);
-        half_accumulate<D4, Q, 0>(qreg, xa, acc);
-        lds_row<HV>(xa, buf + min(r + 1, kTileRows - 1) * V4);
-        half_accumulate<D4, Q, 1>(qreg, xb, acc);
+        const uint4 *row = buf + r * V4;
+        const uint4 *nxt = buf + min(r + 1, kTileRows - 1) * V4;
+        lds_row<CV>(xb, row + CV);
+        chunk_accumulate<D4, Q, NCH, 0>(qreg, xa, acc);
+        if constexpr (NCH == 2) {
+          lds_row<CV>(xa, nxt);
+          chunk_accumulate<D4, Q, NCH, 1>(qreg, xb, acc);
+        } else {
+          lds_row<CV>(xa, row + 2 * CV);
+          chunk_accumulate<D4, Q, NCH, 1>(qreg, xb, acc);
+          lds_row<CV>(xb, row + 3 * CV);
+          chunk_accumulate<D4, Q, NCH, 2>(qreg, xa, acc);
+          lds_row<CV>(xa, nxt);
+          chunk_accumulate<D4, Q, NCH, 3>(qreg, xb, acc);
+        }
         lazy_top2<Q>(acc, k1, k2);
       }
     } else {
