@@ -13,6 +13,7 @@
 #include <cstring>
 #include <atomic>
 #include <exception>
+#include <initializer_list>
 #include <map>
 #include <new>
 #include <mutex>
@@ -275,6 +276,44 @@ struct DevBuf {
   }
 };
 
+// A caller's fresh result array (np.empty) has no pages yet: the device-to-host copy then
+// runs at the page-fault rate (~11 GB/s measured) instead of the link rate.  Large outputs are
+// therefore touched -- one byte per page, from a few threads -- while the inputs travel and the
+// kernels run; the contents of an output buffer are undefined before the call returns, so
+// writing to it early is allowed.  Skipped when the output overlaps an input.
+class HostPrefault {
+ public:
+  HostPrefault(void *dst, size_t bytes, std::initializer_list<std::pair<const void *, size_t>> inputs) {
+    constexpr size_t kMin = (size_t)16 << 20, kPage = 4096;
+    if (!dst || bytes < kMin) return;
+    const char *lo = static_cast<const char *>(dst), *hi = lo + bytes;
+    for (const auto &in : inputs) {
+      const char *a = static_cast<const char *>(in.first);
+      if (a && a < hi && a + in.second > lo) return;
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int T = (int)std::min<size_t>(std::min<unsigned>(8u, hw), bytes / kMin + 1);
+    const size_t per = round_up((bytes + T - 1) / T, kPage);
+    try {
+      for (int i = 0; i < T; ++i)
+        threads_.emplace_back([=] {
+          volatile char *p = static_cast<volatile char *>(dst);
+          for (size_t off = per * i; off < std::min(bytes, per * (i + 1)); off += kPage) p[off] = 0;
+        });
+    } catch (...) {  // could not start a thread: the copy simply faults the pages itself
+    }
+  }
+  void wait() {
+    for (auto &t : threads_)
+      if (t.joinable()) t.join();
+    threads_.clear();
+  }
+  ~HostPrefault() { wait(); }
+
+ private:
+  std::vector<std::thread> threads_;
+};
+
 #define SPV_TRY(expr)          \
   do {                         \
     int _s = (expr);           \
@@ -292,6 +331,8 @@ int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yr
   SPV_TRY(use_device(dev));
   const size_t xb = (size_t)xrows * dim, yb = (size_t)yrows * dim;
   const size_t wsb = spv_l1k2_workspace_bytes(xrows, yrows, dim);
+  HostPrefault touch_idx(idx, (size_t)yrows * 2 * sizeof(uint64_t), {{x, xb}, {y, yb}});
+  HostPrefault touch_dist(dist, (size_t)yrows * 2 * sizeof(int32_t), {{x, xb}, {y, yb}});
   DevBuf dx, dy, di, dd, ws;
   SPV_TRY(dx.alloc(xb));
   SPV_TRY(dy.alloc(yb));
@@ -303,6 +344,8 @@ int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yr
   SPV_HIP_CHECK(hipMemcpyAsync(dy.p, y, yb, hipMemcpyHostToDevice, st));
   SPV_TRY(l1k2_run(dx.as<uint8_t>(), dy.as<uint8_t>(), xrows, yrows, dim, di.as<uint64_t>(),
                    dd.as<int32_t>(), ws.p, wsb, st));
+  touch_idx.wait();
+  touch_dist.wait();
   SPV_HIP_CHECK(hipMemcpyAsync(idx, di.p, (size_t)yrows * 2 * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dist, dd.p, (size_t)yrows * 2 * sizeof(int32_t),
@@ -342,6 +385,7 @@ int host_cascade_one(int dev, const float *x, const float *y, int xrows, int yro
   const size_t xb = (size_t)xrows * dim * sizeof(float), yb = (size_t)yrows * dim * sizeof(float);
   const size_t db = (size_t)n * dim * m * sizeof(float);
   const size_t wsb = cascade_workspace_bytes(xrows, yrows, dim, m, n, g);
+  HostPrefault touch_idx(idx, (size_t)yrows * 2 * sizeof(uint64_t), {{x, xb}, {y, yb}});
   DevBuf dx, dy, dd, di, dds, dn, ws;
   SPV_TRY(dx.alloc(xb));
   SPV_TRY(dy.alloc(yb));
@@ -356,6 +400,7 @@ int host_cascade_one(int dev, const float *x, const float *y, int xrows, int yro
   SPV_HIP_CHECK(hipMemcpyAsync(dd.p, dict, db, hipMemcpyHostToDevice, st));
   SPV_TRY(cascade_run(dx.as<float>(), dy.as<float>(), xrows, yrows, dim, m, n, g, dd.as<float>(),
                       di.as<uint64_t>(), dds.as<float>(), dn.as<int32_t>(), ws.p, wsb, st));
+  touch_idx.wait();
   SPV_HIP_CHECK(hipMemcpyAsync(idx, di.p, (size_t)yrows * 2 * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dist, dds.p, (size_t)yrows * 2 * sizeof(float),
@@ -385,6 +430,7 @@ int host_dlt_one(int dev, const double *P0, const double *P1, int npt, const dou
   SPV_TRY(use_device(dev));
   const size_t ib = (size_t)npt * 3 * sizeof(double);
   const size_t ob = (size_t)npt * (want_error ? 1 : 4) * sizeof(double);
+  HostPrefault touch(dst, ob, {{x, ib}, {xp, ib}});
   DevBuf dx, dxp, dd;
   SPV_TRY(dx.alloc(ib));
   SPV_TRY(dxp.alloc(ib));
@@ -393,6 +439,7 @@ int host_dlt_one(int dev, const double *P0, const double *P1, int npt, const dou
   SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
   SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, xp, ib, hipMemcpyHostToDevice, st));
   SPV_TRY(dlt_run(P0, P1, npt, dx.as<double>(), dxp.as<double>(), dd.as<double>(), want_error, st));
+  touch.wait();
   SPV_HIP_CHECK(hipMemcpyAsync(dst, dd.p, ob, hipMemcpyDeviceToHost, st));
   SPV_HIP_CHECK(hipStreamSynchronize(st));
   return SPV_OK;
