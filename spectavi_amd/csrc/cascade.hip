@@ -28,7 +28,7 @@
 //                     (dist, idx) keys
 //   7 probe_refine    one wave per query (the first design, issue-bound): used when
 //                     kernel 6 does not apply -- full-code check (m > 22) or rows wider
-//                     than 256 bytes
+//                     than 256 bytes (up to 2048)
 //
 // Candidate semantics (closed form of filter_potential_neighbours, :208-227):
 // database row k is a candidate of query i iff for some table j
@@ -1106,8 +1106,8 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
 
   const dim3 grid((yrows + kThreads / 64 - 1) / (kThreads / 64)), block(kThreads);
   const int cpl = (dim / 16 + 7) / 8;
-  if (cpl > 4)
-    return set_error(SPV_ERR_INVALID, "dim=%d > 512 is not supported by the cascade refine kernel",
+  if (cpl > 16)
+    return set_error(SPV_ERR_INVALID, "dim=%d > 2048 is not supported by the cascade refine kernel",
                      dim);
   ProfScope prof_probe("cascade_probe_refine", stream);
   // group-per-query kernel unless the full-code check is needed (m > bucket bits) or rows
@@ -1147,8 +1147,12 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
       SPV_LAUNCH_PROBE(1, 4);
   } else if (cpl == 2) {
     SPV_LAUNCH_PROBE(2, 4);
-  } else {
+  } else if (cpl <= 4) {
     SPV_LAUNCH_PROBE(4, 2);
+  } else if (cpl <= 8) {
+    SPV_LAUNCH_PROBE(8, 1);   // rows up to 1024 bytes
+  } else {
+    SPV_LAUNCH_PROBE(16, 1);  // rows up to 2048 bytes, the widest the L1 kernels take as well
   }
 #undef SPV_LAUNCH_PROBE
   SPV_HIP_CHECK(hipGetLastError());

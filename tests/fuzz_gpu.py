@@ -47,7 +47,7 @@ def fuzz_cascade(seed, budget, only_case=None):
     t0, n = time.time(), 0 if only_case is None else only_case
     while time.time() - t0 < budget:
         rng = np.random.default_rng([seed, 1, n])  # every case is reproducible on its own
-        dim = int(rng.choice([16, 32, 64, 128, 144, 256]))
+        dim = int(rng.choice([16, 32, 64, 128, 144, 256, 128, 128, 400, 512, 1040, 2048]))
         m = int(rng.choice([1, 2, 3, 4, 6, 8, 11, 13, 17, 20, 22, 23, 27, 31]))
         nt = int(rng.choice([1, 2, 3, 4, 7, 16]))
         g = int(rng.integers(0, min(m, 6) + 1))

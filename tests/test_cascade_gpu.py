@@ -22,6 +22,7 @@ def test_golden_2k(golden):
     (4000, 500, 128, 3, 1, 1),    # huge buckets: overflows the LDS candidate list
     (3000, 600, 128, 25, 2, 3),   # m > bucket bits: full-code check path
     (50, 40, 16, 4, 2, 2), (1, 5, 32, 4, 2, 1), (0, 5, 32, 4, 2, 1), (900, 300, 256, 7, 2, 2),
+    (700, 200, 384, 6, 2, 2), (600, 150, 512, 6, 3, 1), (500, 120, 1024, 5, 2, 2), (300, 90, 2048, 5, 2, 3),  # wide rows
 ])
 def test_matches_oracle(oracle, m_rows, n_rows, dim, m, n, g):
     from spectavi_amd import feature
