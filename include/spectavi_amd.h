@@ -83,7 +83,8 @@ int spv_microbench_memory(int mode, size_t table_bytes, double *bytes_per_s);
 /* Exact L1 (sum |x-y|) 2-nearest-neighbour of every query row y against every
  * database row x.  Replaces reference src/Spectavi.cpp:284-298
  * (BruteForceNnL1K2::find_neighbours<IdentityFilter>, src/BruteForceNnL1K2.h:84-145).
- *   x: uint8[xrows, dim] database, y: uint8[yrows, dim] queries, dim % 16 == 0.
+ *   x: uint8[xrows, dim] database, y: uint8[yrows, dim] queries, dim % 16 == 0
+ *   (dim <= 2048 on gfx950; wider rows are rejected with SPV_ERR_INVALID).
  *   outidx : callee-allocated size_t[yrows,2]  (col 0 = nearest)
  *   outdist: callee-allocated int  [yrows,2]
  * Result per query = the two smallest (dist, idx) pairs in lexicographic order;
@@ -95,7 +96,7 @@ void nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows,
 
 /* Cascade-hash candidate prefilter + L1 refine.  Replaces reference
  * src/Spectavi.cpp:321-336 (CascadingHashNn, src/CascadingHashNn.h:86-245).
- *   x,y: float32[rows, dim], integer-valued in [-128,127]; dim % 16 == 0.
+ *   x,y: float32[rows, dim], integer-valued in [-128,127]; dim % 16 == 0, dim <= 2048.
  *   k must be 2 (the reference sizes the buffers by k but writes two columns,
  *   src/Spectavi.cpp:329-335); hash_bit_rate m in [1,31]; num_hash_tables n >= 1;
  *   num_candidate_neighbours g in [0, m].
