@@ -9,8 +9,17 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
 resident in HBM: every rank matches its query shard (uint8 [yrows, 128]) against the
 replicated database (uint8 [xrows, 128]) with the hand-written HIP kernels of
 libspectavi.so (exact L1 2-NN), then (N > 1) the packed (idx0, idx1, d0, d1) records are
-gathered on rank 0 over RCCL.  Weak scaling: per-GPU work is fixed (BASELINE.json
-configs[1]: 256k x 256k per GPU), the global query set grows with N.
+gathered on rank 0 over RCCL.
+
+Workloads (BASELINE.json):
+  --gpus 1   1,000,000 x 1,000,000, D=128 -- the shape north_star's target is quoted on
+             ("1 M x 1 M SIFT-128 L1 2-NN"); configs[1] (256k x 256k) is a parity-test case
+             (tests/test_l1k2_gpu.py::test_full_size_properties_256k) and stays reachable with
+             --xrows 262144 --yrows 262144.
+  --gpus N>1 database 4,000,000 rows replicated on every GPU, 500,000 query rows per rank:
+             at N = 8 exactly configs[4] (4M x 4M, query set sharded 8 ways, RCCL gather of
+             (idx0, idx1, d0, d1)).  Weak scaling: per-GPU work is fixed, the global query set
+             grows with N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
 and `cpu_baseline` objects.  The CPU baseline leg is the only place the oracle is used (its
@@ -43,14 +52,34 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--xrows", type=int, default=262144, help="database rows (replicated)")
-    ap.add_argument("--yrows", type=int, default=262144, help="query rows PER GPU")
+    ap.add_argument("--xrows", type=int, default=None,
+                    help="database rows (replicated); default 1,000,000 at --gpus 1, 4,000,000 otherwise")
+    ap.add_argument("--yrows", type=int, default=None,
+                    help="query rows PER GPU; default 1,000,000 at --gpus 1, 500,000 otherwise")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target wall time of the CPU baseline sample (0 disables it)")
     ap.add_argument("--verify", type=int, default=64,
                     help="queries of the CPU-baseline sample also compared with the GPU result (0 = none)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.xrows is None:
+        a.xrows = 1_000_000 if a.gpus == 1 else 4_000_000
+    if a.yrows is None:
+        a.yrows = 1_000_000 if a.gpus == 1 else 500_000
+    return a
+
+
+def workload_name(xrows, yrows, dim, world):
+    if (xrows, yrows, dim, world) == (1_000_000, 1_000_000, 128, 1):
+        tag = "north_star target shape 1M x 1M"
+    elif (xrows, yrows, dim) == (262144, 262144, 128):
+        tag = "BASELINE configs[1]"
+    elif (xrows, yrows, dim) == (4_000_000, 500_000, 128):
+        tag = ("BASELINE configs[4]: 4M x 4M over 8 GPUs" if world == 8 else
+               "one-eighth shards of BASELINE configs[4] (4M-row database, 500k queries per GPU), %d of 8 shards" % world)
+    else:
+        tag = "custom shape"
+    return "L1 2-NN all-pairs, %d database rows x %d query rows per GPU, D=%d uint8 (%s)" % (xrows, yrows, dim, tag)
 
 
 def cpu_baseline(x_host, y_host, target_s, gpu_idx=None, gpu_dist=None, nverify=0):
@@ -91,9 +120,10 @@ def load_traffic(xrows, yrows, dim):
     (profiles/l1k2_pmc.json, written by tools/pmc_summary.py), if it matches this workload."""
     path = os.path.join(ROOT, "profiles", "l1k2_pmc.json")
     try:
-        rec = json.load(open(path))
-        if (rec.get("xrows"), rec.get("yrows"), rec.get("dim")) == (xrows, yrows, dim):
-            return rec.get("hbm_bytes_per_launch")
+        doc = json.load(open(path))
+        for rec in doc.get("records", [doc]):
+            if (rec.get("xrows"), rec.get("yrows"), rec.get("dim")) == (xrows, yrows, dim):
+                return rec.get("hbm_bytes_per_launch")
     except Exception:
         pass
     return None
@@ -224,8 +254,7 @@ def main():
             "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "L1 2-NN all-pairs, %d x %d per GPU, D=%d uint8 (BASELINE configs[1])"
-                                   % (args.xrows, args.yrows, args.dim),
+            "config": {"workload": workload_name(args.xrows, args.yrows, args.dim, world),
                        "xrows": args.xrows, "yrows_per_gpu": args.yrows, "dim": args.dim,
                        "parallelism": "query-shard x%d, database replicated, RCCL gather of 16 B records" % world},
             "roofline": roofline, "cpu_baseline": cpu, "verified_vs_oracle": verified,

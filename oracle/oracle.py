@@ -3,7 +3,11 @@
 TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py; never from spectavi_amd/ (the product path has no
 CPU fallback).  Each C function cites the reference lines it restates in its
-own header (oracle_l1k2.cpp, oracle_cascade.cpp, oracle_dlt.cpp).
+own header (oracle_l1k2.cpp, oracle_cascade.cpp, oracle_jacobisvd.cpp).  The DLT rows have two
+CPU sides: `dlt_*`, `essential_to_cameras`, `process_fundamental_matrix`, `jacobisvd` are the
+ORACLE (oracle_jacobisvd.cpp: the reference's arithmetic including Eigen's two-sided JacobiSVD);
+`dlt_mirror_*` (oracle_dlt_mirror.cpp) is a host mirror of the HIP kernel's own operation
+sequence, good only for bit-reproducibility checks.
 
 The numpy helpers at the bottom are a *second*, independent statement of the
 same results (the same role `brute_force_nn_batched` plays in the reference's
@@ -17,14 +21,23 @@ import numpy as np
 from numpy.ctypeslib import ndpointer
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_LIB_PATH = os.environ.get("SPECTAVI_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
     """Compile liboracle.so with the committed Makefile (gcc only, no GPU)."""
-    if force or not os.path.exists(_LIB_PATH):
+    if force or not os.path.exists(_LIB_PATH) or _stale():
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
+
+
+def _stale():
+    """liboracle.so older than one of its sources (a checkout that moved on): rebuild."""
+    if os.environ.get("SPECTAVI_ORACLE_LIB"):
+        return False
+    t = os.path.getmtime(_LIB_PATH)
+    return any(os.path.getmtime(os.path.join(_HERE, f)) > t for f in os.listdir(_HERE)
+               if f.endswith(".cpp") or f == "Makefile")
 
 
 _lib = None
@@ -49,14 +62,28 @@ def lib():
         L.oracle_nn_cascading_hash.argtypes = [
             f32, f32, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, f32, u64, f32,
             ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]
-        for name in ("oracle_dlt_triangulate", "oracle_dlt_reprojection_error"):
+        for name in ("oracle_dlt_triangulate", "oracle_dlt_reprojection_error",
+                     "oracle_dlt_mirror_triangulate", "oracle_dlt_mirror_reprojection_error"):
             fn = getattr(L, name)
             fn.restype = None
             fn.argtypes = [f64, f64, ct.c_int, f64, f64, f64]
-        L.oracle_dlt_cheirality.restype = None
-        L.oracle_dlt_cheirality.argtypes = [f64, f64, ct.c_int, f64, f64, u8]
+        for name in ("oracle_dlt_cheirality", "oracle_dlt_mirror_cheirality"):
+            fn = getattr(L, name)
+            fn.restype = None
+            fn.argtypes = [f64, f64, ct.c_int, f64, f64, u8]
+        L.oracle_dlt_mirror_score_hypotheses.restype = None
+        L.oracle_dlt_mirror_score_hypotheses.argtypes = [f64, f64, ct.c_int, ct.c_int, f64, f64, ct.c_double, i32, u8]
         L.oracle_dlt_score_hypotheses.restype = None
-        L.oracle_dlt_score_hypotheses.argtypes = [f64, f64, ct.c_int, ct.c_int, f64, f64, ct.c_double, i32, u8]
+        L.oracle_dlt_score_hypotheses.argtypes = [f64, f64, ct.c_int, ct.c_int, f64, f64, ct.c_double, i32, u8,
+                                                  ct.c_void_p]
+        L.oracle_jacobisvd.restype = ct.c_int
+        L.oracle_jacobisvd.argtypes = [f64, ct.c_int, f64, f64, f64]
+        L.oracle_essential_to_cameras.restype = None
+        L.oracle_essential_to_cameras.argtypes = [f64, f64]
+        L.oracle_process_fundamental_matrix.restype = ct.c_int
+        L.oracle_process_fundamental_matrix.argtypes = [
+            f64, ct.c_double, f64, f64, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
+            ct.POINTER(ct.c_int32), f64, i32, ct.POINTER(ct.c_double), f64, i32]
         L.oracle_max_threads.restype = ct.c_int
         _lib = L
     return _lib
@@ -121,6 +148,8 @@ def _dlt_args(P0, P1, x, xp):
 
 
 def dlt_triangulate(P0, P1, x, xp):
+    """X = V.col(3) of JacobiSVD(A) as the reference computes it (src/DltTriangulator.h:36-58),
+    with the sign this restatement of Eigen's two-sided Jacobi leaves (NOT canonicalised)."""
     P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
     dst = np.empty((x.shape[0], 4))
     lib().oracle_dlt_triangulate(P0, P1, x.shape[0], x, xp, dst)
@@ -128,6 +157,7 @@ def dlt_triangulate(P0, P1, x, xp):
 
 
 def dlt_reprojection_error(P0, P1, x, xp):
+    """Reference src/DltTriangulator.h:67-74 on top of `dlt_triangulate`."""
     P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
     dst = np.empty((x.shape[0], 1))
     lib().oracle_dlt_reprojection_error(P0, P1, x.shape[0], x, xp, dst)
@@ -135,21 +165,105 @@ def dlt_reprojection_error(P0, P1, x, xp):
 
 
 def dlt_cheirality(P0, P1, x, xp):
+    """Reference src/DltTriangulator.h:76-86 (is_infront_both_cameras)."""
     P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
     out = np.empty(x.shape[0], np.uint8)
     lib().oracle_dlt_cheirality(P0, P1, x.shape[0], x, xp, out)
     return out.astype(bool)
 
 
-def dlt_score_hypotheses(P0, P1s, x, xp, max_error):
-    """(counts int32[H], mask bool[H,npt]) -- restates reference src/RansacFitter.h:59-95."""
+def dlt_score_hypotheses(P0, P1s, x, xp, max_error, return_err=False):
+    """(counts int32[H], mask bool[H,npt][, err float64[H,npt]]) -- restates reference
+    src/RansacFitter.h:59-95 (JacobiSVD solve per point and hypothesis)."""
     P1s = np.ascontiguousarray(P1s, dtype=np.float64).reshape(-1, 3, 4)
     P0, _, x, xp = _dlt_args(P0, P1s[0] if len(P1s) else np.zeros((3, 4)), x, xp)
     counts = np.zeros(P1s.shape[0], np.int32)
     mask = np.zeros((P1s.shape[0], x.shape[0]), np.uint8)
+    err = np.zeros((P1s.shape[0], x.shape[0]))
     lib().oracle_dlt_score_hypotheses(P0, P1s.reshape(-1, 12), P1s.shape[0], x.shape[0], x, xp,
-                                      float(max_error), counts, mask.reshape(-1))
+                                      float(max_error), counts, mask.reshape(-1), err.ctypes.data)
+    return (counts, mask.astype(bool), err) if return_err else (counts, mask.astype(bool))
+
+
+def jacobisvd(A):
+    """(U, S, V, sweeps): Eigen::JacobiSVD(A, ComputeFullU | ComputeFullV) restated, A 3x3 or 4x4."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    assert A.shape == (n, n) and n in (3, 4)
+    U, S, V = np.empty((n, n)), np.empty(n), np.empty((n, n))
+    sweeps = lib().oracle_jacobisvd(A, n, U, S, V)
+    return U, S, V, sweeps
+
+
+def essential_to_cameras(E):
+    """Reference src/Camera.h:31-46: the four candidate second cameras [4,3,4] of E."""
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    assert E.shape == (3, 3)
+    cams = np.empty((4, 3, 4))
+    lib().oracle_essential_to_cameras(E, cams)
+    return cams
+
+
+def process_fundamental_matrix(F, x0, x1, singular_value_ratio_allowed=3e-2, required_percent_inliers=0.5,
+                               reprojection_error_allowed=1e-2, find_best_even_in_failure=False):
+    """Reference src/RansacFitter.h:42-95 for one candidate F.  Returns a dict: success,
+    inlier_count, best_P [3,4], inlier_idx, gate_ratio, E, counts4 (per camera, -1 if gated)."""
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    assert F.shape == (3, 3) and x0.shape == x1.shape and x0.shape[1] == 3
+    npt = x0.shape[0]
+    cnt, ratio = ct.c_int32(0), ct.c_double(0.0)
+    best_P, E = np.zeros((3, 4)), np.zeros((3, 3))
+    idx, counts4 = np.zeros(max(npt, 1), np.int32), np.zeros(4, np.int32)
+    ok = lib().oracle_process_fundamental_matrix(
+        F, float(singular_value_ratio_allowed), x0, x1, npt, float(required_percent_inliers),
+        float(reprojection_error_allowed), int(bool(find_best_even_in_failure)), ct.byref(cnt), best_P, idx,
+        ct.byref(ratio), E, counts4)
+    return {"success": bool(ok), "inlier_count": int(cnt.value) if ok else 0, "best_P": best_P if ok else None,
+            "inlier_idx": idx[:cnt.value].copy() if ok else np.zeros(0, np.int32), "gate_ratio": float(ratio.value),
+            "E": E, "counts4": counts4}
+
+
+# ---- host mirror of the HIP kernels' operation sequence (bit-reproducibility only) -------------
+def dlt_mirror_triangulate(P0, P1, x, xp):
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    dst = np.empty((x.shape[0], 4))
+    lib().oracle_dlt_mirror_triangulate(P0, P1, x.shape[0], x, xp, dst)
+    return dst
+
+
+def dlt_mirror_reprojection_error(P0, P1, x, xp):
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    dst = np.empty((x.shape[0], 1))
+    lib().oracle_dlt_mirror_reprojection_error(P0, P1, x.shape[0], x, xp, dst)
+    return dst
+
+
+def dlt_mirror_cheirality(P0, P1, x, xp):
+    P0, P1, x, xp = _dlt_args(P0, P1, x, xp)
+    out = np.empty(x.shape[0], np.uint8)
+    lib().oracle_dlt_mirror_cheirality(P0, P1, x.shape[0], x, xp, out)
+    return out.astype(bool)
+
+
+def dlt_mirror_score_hypotheses(P0, P1s, x, xp, max_error):
+    P1s = np.ascontiguousarray(P1s, dtype=np.float64).reshape(-1, 3, 4)
+    P0, _, x, xp = _dlt_args(P0, P1s[0] if len(P1s) else np.zeros((3, 4)), x, xp)
+    counts = np.zeros(P1s.shape[0], np.int32)
+    mask = np.zeros((P1s.shape[0], x.shape[0]), np.uint8)
+    lib().oracle_dlt_mirror_score_hypotheses(P0, P1s.reshape(-1, 12), P1s.shape[0], x.shape[0], x, xp,
+                                             float(max_error), counts, mask.reshape(-1))
     return counts, mask.astype(bool)
+
+
+def canonical_sign(X):
+    """The HIP path's sign convention (X[3] >= 0, else first nonzero component > 0) applied to
+    rows of X: the reference leaves the sign of V.col(3) to Eigen (parity unpinned)."""
+    X = np.array(X, dtype=np.float64, copy=True)
+    lead = np.where(X[:, 3] != 0, X[:, 3], np.where(X[:, 0] != 0, X[:, 0], np.where(X[:, 1] != 0, X[:, 1], X[:, 2])))
+    X[lead < 0] *= -1
+    return X
 
 
 # ----------------------------------------------------------------------------------

@@ -1,29 +1,17 @@
-// oracle_dlt.cpp -- CPU restatement of the reference's two-view DLT triangulation.
+// oracle_dlt_mirror.cpp -- host-side MIRROR of the HIP DLT kernels' own operation sequence.
 //
 // TEST INFRASTRUCTURE ONLY (see oracle_l1k2.cpp header): never imported, linked
 // or called from spectavi_amd/.
 //
-// Follows (read as text, restated, not copied):
-//   reference src/DltTriangulator.h:36-65  solve: hnormalize both observations
-//       (:38-45), A rows u*P[2]-P[0], v*P[2]-P[1] per view (:51-54), X = right
-//       singular vector of the smallest singular value (:56-58), reprojections (:61-62)
-//   reference src/DltTriangulator.h:67-74  reprojection_error: sum of the two
-//       Euclidean pixel distances
-//   reference src/DltTriangulator.h:76-86  cheirality (distance2camera*, not exported
-//       through the C-ABI; provided for the RANSAC-scoring "next" row)
-//   reference src/Spectavi.cpp:38-68        the serial per-point loops
-//
-// The SVD itself lives in Eigen (JacobiSVD, version unpinned by the reference
-// build, absent here).  Only its result matters -- the unit right singular vector of the
-// smallest singular value -- and it is restated two ways (square-root-free Gram-Schmidt +
-// inverse iteration with a one-sided Hestenes Jacobi fallback; Jacobi alone for RANSAC scoring)
-// in fp64 -- the same operation sequence the HIP kernel executes, fused
-// multiply-adds written explicitly and implicit contraction disabled on both sides -- and pinned two ways in
-// tests/test_oracle.py: (a) the reference's own test properties
-// (test/test_mvg.py:94-125: reprojection error < 1e-3 and X == X0 up to scale on
-// noise-free random cameras), (b) numpy.linalg.svd (LAPACK) null vectors of the
-// same A.  PARITY UNPINNED: the sign of X (arbitrary in Eigen); canonicalised
-// here and in the HIP path to X[3] >= 0.
+// THIS IS NOT THE ORACLE for the DLT rows: it executes, with std::fma, exactly the sequence of
+// IEEE operations spectavi_amd/csrc/dlt.hip executes (square-root-free Gram-Schmidt + inverse
+// iteration with a one-sided Hestenes Jacobi fallback; Jacobi alone for RANSAC scoring; sign
+// canonicalised to X[3] >= 0), so that "device == host, bit for bit" can be asserted: that pins
+// determinism of the device code (no miscompiled FMA contraction, no lane-dependent path, inf/nan
+// in the same places), NOT that X is the right singular vector of the smallest singular value.
+// Correctness of the HIP path is judged against oracle_jacobisvd.cpp (the restatement of the
+// reference's Eigen::JacobiSVD arithmetic, src/DltTriangulator.h:36-86) and against LAPACK in
+// tests/test_dlt_gpu.py, tests/fuzz_gpu.py and tests/test_oracle.py.
 
 #include <cmath>
 #include <cstdint>
@@ -215,7 +203,7 @@ inline double det3(const double *P) {
 extern "C" {
 
 // dst: double[npt,4].  Serial loop, as reference src/Spectavi.cpp:48-51.
-void oracle_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
+void oracle_dlt_mirror_triangulate(const double *P0, const double *P1, int npt, const double *x,
                             const double *xp, double *dst) {
   for (int i = 0; i < npt; ++i) {
     Solve s;
@@ -225,7 +213,7 @@ void oracle_dlt_triangulate(const double *P0, const double *P1, int npt, const d
 }
 
 // dst: double[npt].  As reference src/Spectavi.cpp:64-67.
-void oracle_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
+void oracle_dlt_mirror_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                                    const double *xp, double *dst) {
   for (int i = 0; i < npt; ++i) {
     Solve s;
@@ -241,7 +229,7 @@ void oracle_dlt_reprojection_error(const double *P0, const double *P1, int npt, 
 
 // infront: uint8[npt], 1 iff the point is in front of both cameras
 // (reference src/DltTriangulator.h:76-86).
-void oracle_dlt_cheirality(const double *P0, const double *P1, int npt, const double *x,
+void oracle_dlt_mirror_cheirality(const double *P0, const double *P1, int npt, const double *x,
                            const double *xp, uint8_t *infront) {
   const double s0 = det3(P0) < 0 ? -1.0 : 1.0, s1 = det3(P1) < 0 ? -1.0 : 1.0;
   const double n0 = P0[2] * P0[2] + P0[6] * P0[6] + P0[10] * P0[10];
@@ -261,7 +249,7 @@ void oracle_dlt_cheirality(const double *P0, const double *P1, int npt, const do
 // RANSAC hypothesis scoring: counts int32[nhyp], mask uint8[nhyp,npt] (may be NULL).
 // Restates the two scoring loops of reference src/RansacFitter.h:59-73 and :86-94
 // (inlier iff reprojection_error() <= max_error && is_infront_both_cameras()).
-void oracle_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
+void oracle_dlt_mirror_score_hypotheses(const double *P0, const double *P1s, int nhyp, int npt,
                                  const double *x, const double *xp, double max_error,
                                  int32_t *counts, uint8_t *mask) {
   for (int h = 0; h < nhyp; ++h) {

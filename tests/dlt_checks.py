@@ -1,0 +1,124 @@
+"""Independent checks of a DLT result against the reference's DEFINITION, with LAPACK as the solver.
+
+The reference computes X = V.col(3) of the SVD of the 4x4 DLT matrix A (src/DltTriangulator.h:51-58):
+the unit right singular vector of the smallest singular value, sign arbitrary.  These helpers
+restate that definition with numpy.linalg.svd (LAPACK, importable on the GPU box) so that the HIP
+path -- which does not run an SVD at all on its fast path (Gram-Schmidt + inverse iteration) -- is
+judged by something that shares no code and no algorithm with it:
+
+  residual     ||A X||_2 <= sigma4 (1 + 1e-9) + 1e-13 ||A||_2          (every finite point)
+  direction    |<X, v4>| >= 1 - 1e-9      where (sigma3 - sigma4) / sigma1 > 1e-6
+               (below that gap v4 itself is ill-determined: any unit vector of the near-null plane
+               with a small residual is as good an answer, and the residual test is what holds)
+  unit norm    | ||X|| - 1 | <= 1e-12
+  error        the reprojection error (src/DltTriangulator.h:67-74) agrees within 1e-6 relative
+               (north_star's float tolerance) + a conditioning-scaled absolute term with the value
+               recomputed from LAPACK's v4, on the well-separated points.
+
+Used by tests/test_dlt_gpu.py, tests/fuzz_gpu.py (GPU) and tests/test_oracle.py (CPU, on the oracle
+and on the host mirror of the kernel's operation sequence)."""
+import numpy as np
+
+GAP = 1e-6
+
+
+def dlt_matrices(P0, P1, x, xp):
+    """A [npt,4,4] and the hnormalised observations (u, v, up, vp), as src/DltTriangulator.h:38-54."""
+    P0, P1 = np.asarray(P0, np.float64), np.asarray(P1, np.float64)
+    x, xp = np.atleast_2d(np.asarray(x, np.float64)), np.atleast_2d(np.asarray(xp, np.float64))
+    with np.errstate(all="ignore"):
+        u, v = x[:, 0] / x[:, 2], x[:, 1] / x[:, 2]
+        up, vp = xp[:, 0] / xp[:, 2], xp[:, 1] / xp[:, 2]
+        A = np.stack([u[:, None] * P0[2] - P0[0], v[:, None] * P0[2] - P0[1],
+                      up[:, None] * P1[2] - P1[0], vp[:, None] * P1[2] - P1[1]], axis=1)
+    return A, (u, v, up, vp)
+
+
+def reprojection_error(P0, P1, X, obs):
+    """src/DltTriangulator.h:61-62, 67-74 for rows of X."""
+    u, v, up, vp = obs
+    with np.errstate(all="ignore"):
+        r0, r1 = X @ np.asarray(P0).T, X @ np.asarray(P1).T
+        e0 = np.hypot(r0[:, 0] / r0[:, 2] - u, r0[:, 1] / r0[:, 2] - v)
+        e1 = np.hypot(r1[:, 0] / r1[:, 2] - up, r1[:, 1] / r1[:, 2] - vp)
+    return e0 + e1, r0[:, 2], r1[:, 2]
+
+
+def lapack_svd(A):
+    """(S [n,4] descending, V4 [n,4]) for the finite matrices of A; rows of non-finite ones are nan."""
+    n = A.shape[0]
+    S = np.full((n, 4), np.nan)
+    V4 = np.full((n, 4), np.nan)
+    ok = np.isfinite(A).all(axis=(1, 2))
+    if ok.any():
+        _, s, vt = np.linalg.svd(A[ok])
+        S[ok], V4[ok] = s, vt[:, 3, :]
+    return S, V4, ok
+
+
+def check_definition(X, P0, P1, x, xp, err=None, what="X"):
+    """Assert the definition above for rows of X (and, if given, the reprojection errors `err`).
+    Non-finite inputs (w = 0, inf, nan observations) are skipped: the reference's JacobiSVD leaves
+    them unspecified.  Returns a dict of the worst margins seen."""
+    X = np.asarray(X, np.float64)
+    A, obs = dlt_matrices(P0, P1, x, xp)
+    S, V4, ok = lapack_svd(A)
+    ok &= np.isfinite(X).all(axis=1)
+    stats = {"points": int(ok.sum()), "well_separated": 0, "worst_residual_excess": 0.0, "worst_direction": 0.0,
+             "worst_err_rel": 0.0}
+    if not ok.any():
+        return stats
+    Xo, Ao, So, Vo = X[ok], A[ok], S[ok], V4[ok]
+    nrm = np.linalg.norm(Xo, axis=1)
+    assert np.max(np.abs(nrm - 1)) <= 1e-12, "%s: not unit norm (worst %.3e)" % (what, np.max(np.abs(nrm - 1)))
+    resid = np.linalg.norm(np.einsum("nij,nj->ni", Ao, Xo), axis=1)
+    bound = So[:, 3] * (1 + 1e-9) + 1e-13 * So[:, 0]
+    excess = resid - bound
+    stats["worst_residual_excess"] = float(np.max(excess / np.maximum(So[:, 0], 1e-300)))
+    bad = np.flatnonzero(excess > 0)
+    assert bad.size == 0, ("%s: ||A X|| exceeds sigma4 at %d of %d points; worst: resid %.3e sigma %s"
+                           % (what, bad.size, resid.size, resid[bad[np.argmax(excess[bad])]],
+                              So[bad[np.argmax(excess[bad])]]))
+    sep = (So[:, 2] - So[:, 3]) > GAP * So[:, 0]
+    stats["well_separated"] = int(sep.sum())
+    if sep.any():
+        dots = np.abs(np.einsum("ni,ni->n", Xo[sep], Vo[sep]))
+        stats["worst_direction"] = float(np.max(1 - dots))
+        assert np.min(dots) >= 1 - 1e-9, "%s: |<X, v4>| = %.12f at a point with a sigma gap > 1e-6" % (what, np.min(dots))
+    if err is not None:
+        err = np.asarray(err, np.float64).reshape(-1)[ok]
+        e_l, z0, z1 = reprojection_error(P0, P1, Vo, tuple(o[ok] for o in obs))
+        # well-separated points whose reprojected depth is not near zero (the perspective division
+        # amplifies the direction error of X by 1/depth)
+        scale = np.maximum(1.0, np.max(np.abs(np.stack([o[ok] for o in obs])), axis=0))
+        depth_ok = (np.abs(z0) > 1e-3) & (np.abs(z1) > 1e-3)
+        use = sep & depth_ok & np.isfinite(e_l) & np.isfinite(err)
+        if use.any():
+            kappa = So[use, 0] / (So[use, 2] - So[use, 3])
+            atol = 1e-13 * kappa * scale[use] / np.minimum(np.abs(z0[use]), np.abs(z1[use]))
+            diff = np.abs(err[use] - e_l[use])
+            tol = 1e-6 * e_l[use] + atol
+            stats["worst_err_rel"] = float(np.max(diff / np.maximum(tol, 1e-300)))
+            assert np.all(diff <= tol), ("%s: reprojection error differs from the LAPACK value by %.3e (tol %.3e)"
+                                         % (what, diff[np.argmax(diff - tol)], tol[np.argmax(diff - tol)]))
+    return stats
+
+
+def check_against_oracle(X, oX, P0, P1, x, xp, what="X"):
+    """X (HIP, sign canonicalised) against the oracle's V.col(3) (Eigen-style JacobiSVD restatement,
+    sign as it falls): equal up to sign within 64 eps sigma1 / (sigma3 - sigma4) on the well-separated
+    finite points.  Returns the worst ratio to that tolerance."""
+    X, oX = np.asarray(X, np.float64), np.asarray(oX, np.float64)
+    A, _ = dlt_matrices(P0, P1, x, xp)
+    S, _, ok = lapack_svd(A)
+    ok &= np.isfinite(X).all(axis=1) & np.isfinite(oX).all(axis=1)
+    ok &= (S[:, 2] - S[:, 3]) > GAP * S[:, 0]
+    if not ok.any():
+        return 0.0
+    sgn = np.sign(np.einsum("ni,ni->n", X[ok], oX[ok]))
+    diff = np.max(np.abs(X[ok] - sgn[:, None] * oX[ok]), axis=1)
+    tol = 64 * np.finfo(np.float64).eps * S[ok, 0] / (S[ok, 2] - S[ok, 3]) + 1e-15
+    worst = float(np.max(diff / tol))
+    assert worst <= 1.0, "%s: differs from the JacobiSVD oracle by %.3e (tol %.3e)" % (
+        what, diff[np.argmax(diff / tol)], tol[np.argmax(diff / tol)])
+    return worst

@@ -204,21 +204,36 @@ def test_extreme_aspect_ratios(oracle):
     assert bool((idx >= 0).all()) and bool((idx < 3).all())
 
 
-def test_config5_database_size(oracle):
-    """BASELINE configs[4] shards 4M queries over 8 GPUs against a replicated 4M-row database.
-    One GPU's database size (4M x 128) with a 2048-query sample of its shard, bit-exact vs the
-    oracle, plus planted exact copies spread over all 64 database slices."""
+def test_config5_full_shard(oracle):
+    """BASELINE configs[4] shards 4M queries over 8 GPUs against a replicated 4M-row database:
+    ONE GPU's full share of it, 4,000,000 database rows x 500,000 query rows (2e12 pairs, ~1.8 s),
+    through size-independent properties -- planted exact copies spread over all 64 database
+    slices come back at distance 0 with the right index, the lower index wins between two exact
+    copies, every row is sorted, in range and distinct, the reported distance of a strided
+    sample of (query, idx) pairs is the true L1 distance -- plus a 1024-query subsample of the
+    shard compared bit for bit with the oracle against the full database."""
     import torch
     from spectavi_amd import device
-    m, n = 4_000_000, 2048
+    m, n = 4_000_000, 500_000
     g = torch.Generator(device="cuda").manual_seed(2026)
     x = torch.randint(0, 256, (m, 128), dtype=torch.uint8, device="cuda", generator=g)
     y = torch.randint(0, 256, (n, 128), dtype=torch.uint8, device="cuda", generator=g)
-    src = (torch.arange(0, 64, device="cuda") * 62_497 + 11) % m
-    y[:64] = x[src]
+    planted = torch.arange(0, 4096, device="cuda") * 122 + 7          # query rows
+    src = (torch.arange(0, 4096, device="cuda") * 976_553 + 11) % m    # database rows, all slices
+    y[planted] = x[src]
+    x[3_999_999] = y[499_999]   # two exact copies of the last query: the last database row ...
+    x[17] = y[499_999]          # ... and an early one; the lower index must come first
     idx, dist = device.l1k2(x, y)
     torch.cuda.synchronize()
-    assert bool((dist[:64, 0] == 0).all()) and bool((idx[:64, 0] == src).all())
-    oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y.cpu().numpy(), nthreads=oracle.max_threads())
-    assert np.array_equal(idx.cpu().numpy().view(np.uint64), oidx)
-    assert np.array_equal(dist.cpu().numpy(), odist)
+    assert bool((dist[planted, 0] == 0).all()) and bool((idx[planted, 0] == src).all())
+    assert idx[499_999].tolist() == [17, 3_999_999] and dist[499_999].tolist() == [0, 0]
+    assert bool((dist[:, 0] <= dist[:, 1]).all())
+    assert bool((idx >= 0).all()) and bool((idx < m).all()) and bool((idx[:, 0] != idx[:, 1]).all())
+    sel = torch.arange(0, n, 97, device="cuda")
+    for c in range(2):
+        d = (x[idx[sel, c]].to(torch.int32) - y[sel].to(torch.int32)).abs().sum(1)
+        assert bool((d == dist[sel, c]).all())
+    sub = np.concatenate([np.arange(0, n, 489), [499_999]])
+    oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y[sub].cpu().numpy(), nthreads=oracle.max_threads())
+    assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist[sub].cpu().numpy(), odist)

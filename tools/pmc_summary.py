@@ -82,7 +82,16 @@ def main():
                              "requests at 64 B (MI355X_MICROARCH.md, HBM)"}
         if fetch is not None and write is not None:
             rec["hbm_bytes_per_launch"] = 1024.0 * (2.0 * fetch + write)
-        json.dump(rec, open(os.path.join(out_dir, "l1k2_pmc.json"), "w"), indent=1)
+        # one record per workload shape; bench.py picks the one matching its run
+        path = os.path.join(out_dir, "l1k2_pmc.json")
+        try:
+            doc = json.load(open(path))
+            records = doc.get("records", [doc])
+        except Exception:
+            records = []
+        records = [r for r in records if (r.get("xrows"), r.get("yrows"), r.get("dim")) != (a.xrows, a.yrows, a.dim)]
+        records.append(rec)
+        json.dump({"records": records}, open(path, "w"), indent=1)
         print(json.dumps(rec))
 
 
