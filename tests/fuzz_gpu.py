@@ -76,40 +76,61 @@ def fuzz_cascade(seed, budget, only_case=None):
     return n
 
 
-def fuzz_dlt(seed, budget, only_case=None):
+def dlt_case(seed, n):
+    """Case n of the DLT fuzz: (P0, P1, x, xp, kind, noise), reproducible on its own."""
+    rng = np.random.default_rng([seed, 2, n])
+    npt = int(rng.choice([1, 2, 63, 64, 65, 255, 257, rng.integers(300, 20000)]))
+    kind = int(rng.integers(0, 6))
+    P0 = rng.standard_normal((3, 4))
+    P1 = rng.standard_normal((3, 4))
+    if kind == 1:
+        P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    if kind == 2:
+        P1 = P0 + 1e-9 * rng.standard_normal((3, 4))       # nearly identical cameras
+    Xw = rng.standard_normal((npt, 4))
+    if kind == 3:
+        Xw[:, 3] = 0.0                                       # points at infinity
+    x, xp = Xw @ P0.T, Xw @ P1.T
+    noise = float(rng.choice([0.0, 1e-6, 1e-3, 0.1, 10.0]))
+    x[:, :2] += noise * rng.standard_normal((npt, 2))
+    xp[:, :2] += noise * rng.standard_normal((npt, 2))
+    if kind == 4:
+        x *= 1e6                                             # large homogeneous scale
+    if kind == 5:
+        x[: max(1, npt // 10)] = xp[: max(1, npt // 10)]    # inconsistent pairs
+    if rng.random() < 0.15:                                  # w = 0 / non-finite observations: inf and nan
+        x[rng.integers(0, npt), 2] = 0.0                     # must come out in the same places on both sides
+        xp[rng.integers(0, npt), 2] = 0.0
+        x[rng.integers(0, npt), 0] = np.inf if rng.random() < 0.5 else np.nan
+    return P0, P1, x, xp, kind, noise
+
+
+def fuzz_dlt(seed, budget, only_case=None, impl=None):
+    """Every case three ways: (a) bit for bit against the host mirror of the kernel's operation
+    sequence (determinism: inf/nan in the same places, no lane- or shape-dependent path); (b) the
+    reference's DEFINITION with LAPACK as the solver (tests/dlt_checks.py: residual <= sigma4,
+    direction where the gap allows, reprojection error within 1e-6 relative); (c) up to sign
+    against the oracle (oracle_jacobisvd.cpp, the reference's JacobiSVD arithmetic restated).
+    `impl` = (triangulate, reprojection_error) replaces the HIP entry points (the CPU suite runs the
+    same cases on the mirror itself)."""
+    from tests import dlt_checks as dc
+    tri, rep = impl or (mvg.dlt_triangulate, mvg.dlt_reprojection_error)
     t0, n = time.time(), 0 if only_case is None else only_case
     while time.time() - t0 < budget:
-        rng = np.random.default_rng([seed, 2, n])  # every case is reproducible on its own
-        npt = int(rng.choice([1, 2, 63, 64, 65, 255, 257, rng.integers(300, 20000)]))
-        kind = int(rng.integers(0, 6))
-        P0 = rng.standard_normal((3, 4))
-        P1 = rng.standard_normal((3, 4))
-        if kind == 1:
-            P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
-        if kind == 2:
-            P1 = P0 + 1e-9 * rng.standard_normal((3, 4))       # nearly identical cameras
-        Xw = rng.standard_normal((npt, 4))
-        if kind == 3:
-            Xw[:, 3] = 0.0                                       # points at infinity
-        x, xp = Xw @ P0.T, Xw @ P1.T
-        noise = float(rng.choice([0.0, 1e-6, 1e-3, 0.1, 10.0]))
-        x[:, :2] += noise * rng.standard_normal((npt, 2))
-        xp[:, :2] += noise * rng.standard_normal((npt, 2))
-        if kind == 4:
-            x *= 1e6                                             # large homogeneous scale
-        if kind == 5:
-            x[: max(1, npt // 10)] = xp[: max(1, npt // 10)]    # inconsistent pairs
-        if rng.random() < 0.15:                                  # w = 0 / non-finite observations: inf and nan
-            x[rng.integers(0, npt), 2] = 0.0                     # must come out in the same places on both sides
-            xp[rng.integers(0, npt), 2] = 0.0
-            x[rng.integers(0, npt), 0] = np.inf if rng.random() < 0.5 else np.nan
-        X = mvg.dlt_triangulate(P0, P1, x, xp)
-        E = mvg.dlt_reprojection_error(P0, P1, x, xp)
-        oX, oE = o.dlt_triangulate(P0, P1, x, xp), o.dlt_reprojection_error(P0, P1, x, xp)
-        if not (np.array_equal(X, oX, equal_nan=True) and np.array_equal(E, oE, equal_nan=True)):
-            bad = int(np.sum(~((X == oX) | (np.isnan(X) & np.isnan(oX))).all(axis=1)))
-            raise SystemExit("DLT MISMATCH case=%d npt=%d kind=%d noise=%g rows_differing=%d maxabs=%g" %
-                             (n, npt, kind, noise, bad, float(np.nanmax(np.abs(X - oX)))))
+        P0, P1, x, xp, kind, noise = dlt_case(seed, n)
+        npt = x.shape[0]
+        X = tri(P0, P1, x, xp)
+        E = rep(P0, P1, x, xp)
+        mX, mE = o.dlt_mirror_triangulate(P0, P1, x, xp), o.dlt_mirror_reprojection_error(P0, P1, x, xp)
+        if not (np.array_equal(X, mX, equal_nan=True) and np.array_equal(E, mE, equal_nan=True)):
+            bad = int(np.sum(~((X == mX) | (np.isnan(X) & np.isnan(mX))).all(axis=1)))
+            raise SystemExit("DLT MISMATCH vs mirror case=%d npt=%d kind=%d noise=%g rows_differing=%d maxabs=%g" %
+                             (n, npt, kind, noise, bad, float(np.nanmax(np.abs(X - mX)))))
+        try:
+            dc.check_definition(X, P0, P1, x, xp, err=E, what="case %d" % n)
+            dc.check_against_oracle(X, o.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp, what="case %d" % n)
+        except AssertionError as e:
+            raise SystemExit("DLT DEFINITION FAILURE npt=%d kind=%d noise=%g: %s" % (npt, kind, noise, e))
         n += 1
         if only_case is not None:
             break
@@ -150,7 +171,8 @@ def fuzz_ratio(seed, budget, only_case=None):
     return n
 
 
-def fuzz_score(seed, budget, only_case=None):
+def fuzz_score(seed, budget, only_case=None, impl=None):
+    score = impl or (lambda *a: mvg.dlt_score_hypotheses(*a, return_mask=True))
     t0, n = time.time(), 0 if only_case is None else only_case
     while time.time() - t0 < budget:
         rng = np.random.default_rng([seed, 4, n])
@@ -170,11 +192,21 @@ def fuzz_score(seed, budget, only_case=None):
         if nhyp > 1:
             P1s[1] = np.hstack([R, -t])                 # behind-the-camera twin
         thr = float(rng.choice([1e-4, 1e-2, 0.5, 1e3]))
-        c, mk = mvg.dlt_score_hypotheses(P0, P1s, x, xp, thr, return_mask=True)
-        oc, omk = o.dlt_score_hypotheses(P0, P1s, x, xp, thr)
-        if not (np.array_equal(c, oc) and np.array_equal(np.asarray(mk, bool), omk)):
-            raise SystemExit("SCORE MISMATCH case=%d npt=%d nhyp=%d thr=%g counts differ at %s" %
-                             (n, npt, nhyp, thr, np.flatnonzero(c != oc)[:5]))
+        c, mk = score(P0, P1s, x, xp, thr)
+        mk = np.asarray(mk, bool)
+        mc, mmk = o.dlt_mirror_score_hypotheses(P0, P1s, x, xp, thr)
+        if not (np.array_equal(c, mc) and np.array_equal(mk, mmk)):
+            raise SystemExit("SCORE MISMATCH vs mirror case=%d npt=%d nhyp=%d thr=%g counts differ at %s" %
+                             (n, npt, nhyp, thr, np.flatnonzero(c != mc)[:5]))
+        # the oracle (JacobiSVD per point and hypothesis): same decisions wherever its own error is
+        # not within 1e-9 relative of the threshold and the solve is well separated enough for the
+        # cheirality sign to be determined (|error| finite)
+        oc, omk, oe = o.dlt_score_hypotheses(P0, P1s, x, xp, thr, return_err=True)
+        clear = np.isfinite(oe) & (np.abs(oe - thr) > 1e-9 * thr)
+        if not np.array_equal(mk[clear], omk[clear]):
+            hh, pp = np.nonzero((mk != omk) & clear)
+            raise SystemExit("SCORE MISMATCH vs oracle case=%d npt=%d nhyp=%d thr=%g first (hyp %d, point %d) err %g" %
+                             (n, npt, nhyp, thr, hh[0], pp[0], oe[hh[0], pp[0]]))
         n += 1
         if only_case is not None:
             break

@@ -83,12 +83,19 @@ def main():
     xp = X @ P1.T
     x[500:, :2] += rng.normal(0, 1e-3, (500, 2)) * x[500:, 2:3]
     xp[500:, :2] += rng.normal(0, 1e-3, (500, 2)) * xp[500:, 2:3]
+    # X / err: the oracle (oracle_jacobisvd.cpp: the reference's arithmetic with Eigen's two-sided
+    # JacobiSVD restated; sign of X as that SVD leaves it).  X_mirror / err_mirror: the host mirror
+    # of the HIP kernel's operation sequence (sign canonicalised to X[3] >= 0), which the kernel must
+    # reproduce bit for bit.  X_lapack: numpy.linalg.svd null vectors, canonical sign.
     tri = o.dlt_triangulate(P0, P1, x, xp)
     err = o.dlt_reprojection_error(P0, P1, x, xp)
+    mir = o.dlt_mirror_triangulate(P0, P1, x, xp)
+    mir_err = o.dlt_mirror_reprojection_error(P0, P1, x, xp)
     ref = o.numpy_dlt_null_vector(P0, P1, x, xp)
-    assert np.allclose(tri, ref, rtol=0, atol=1e-9)
+    assert np.allclose(o.canonical_sign(tri), ref, rtol=0, atol=1e-12)
+    assert np.allclose(mir, ref, rtol=0, atol=1e-12)
     np.savez_compressed(os.path.join(OUT, "dlt_1000.npz"), P0=P0, P1=P1, x=x, xp=xp, X=tri, err=err,
-                        X_lapack=ref)
+                        X_mirror=mir, err_mirror=mir_err, X_lapack=ref)
     # the reference's own golden SIFT table (test/test_feature.py:38-41 loads it with np.loadtxt):
     # a data file, stored here as float32 npz so that GPU tests have real-distribution descriptors
     ref_table = "/root/reference/data/sift-test/sur-ogre.sift"

@@ -1,10 +1,21 @@
-"""GPU parity: batched DLT triangulation through the C-ABI vs the CPU oracle and LAPACK."""
+"""GPU parity: batched DLT triangulation through the C-ABI, judged three ways:
+
+  * the ORACLE (oracle/oracle_jacobisvd.cpp: the reference's arithmetic with Eigen's two-sided
+    JacobiSVD restated), up to the sign of X, within a conditioning-scaled tolerance;
+  * the reference's DEFINITION with LAPACK as the solver (tests/dlt_checks.py): ||A X|| <= sigma4,
+    |<X, v4>| >= 1 - 1e-9 where the singular-value gap allows, reprojection error within 1e-6
+    relative (north_star's float tolerance);
+  * the host MIRROR of the kernel's own operation sequence (oracle/oracle_dlt_mirror.cpp), bit for
+    bit: determinism of the device code, not correctness.
+"""
 import numpy as np
 import pytest
 
+from tests import dlt_checks as dc
+
 pytestmark = pytest.mark.gpu
 
-# fp64 tolerance.  The HIP kernel and the oracle execute the same IEEE operation
+# fp64 tolerance vs the mirror.  The HIP kernel and the mirror execute the same IEEE operation
 # sequence with contraction disabled, so they are expected to agree exactly; the
 # bound below only allows for a non-correctly-rounded device sqrt/div.
 RTOL = 1e-12
@@ -15,11 +26,15 @@ def test_golden(golden):
     g = golden("dlt_1000.npz")
     X = mvg.dlt_triangulate(g["P0"], g["P1"], g["x"], g["xp"])
     assert X.shape == (1000, 4)
-    assert np.max(np.abs(X - g["X"])) <= RTOL
-    assert np.max(np.abs(X - g["X_lapack"])) < 1e-9
+    assert np.max(np.abs(X - g["X_mirror"])) <= RTOL
+    assert np.max(np.abs(X - g["X_lapack"])) < 1e-12
+    sgn = np.sign(np.einsum("ni,ni->n", X, g["X"]))           # oracle: sign as JacobiSVD leaves it
+    assert np.max(np.abs(X - sgn[:, None] * g["X"])) < 1e-12
     err = mvg.dlt_reprojection_error(g["P0"], g["P1"], g["x"], g["xp"])
     assert err.shape == (1000, 1)
-    assert np.max(np.abs(err - g["err"])) <= 1e-9 * max(1.0, float(np.max(g["err"])))
+    assert np.max(np.abs(err - g["err_mirror"])) <= 1e-12 * max(1.0, float(np.max(g["err"])))
+    assert np.allclose(err, g["err"], rtol=1e-6, atol=1e-12)   # oracle, north_star's float tolerance
+    dc.check_definition(X, g["P0"], g["P1"], g["x"], g["xp"], err=err, what="golden")
 
 
 def test_reference_test_properties():
@@ -44,12 +59,16 @@ def test_batch_matches_oracle(oracle):
     x = Xw @ P0.T + rng.normal(0, 1e-3, (100003, 3))
     xp = Xw @ P1.T + rng.normal(0, 1e-3, (100003, 3))
     X = mvg.dlt_triangulate(P0, P1, x, xp)
-    oX = oracle.dlt_triangulate(P0, P1, x, xp)
-    assert np.max(np.abs(X - oX)) <= RTOL
+    assert np.max(np.abs(X - oracle.dlt_mirror_triangulate(P0, P1, x, xp))) <= RTOL
     assert np.max(np.abs(np.linalg.norm(X, axis=1) - 1)) < 1e-12 and np.all(X[:, 3] >= 0)
     e = mvg.dlt_reprojection_error(P0, P1, x, xp)
+    assert np.allclose(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp), rtol=1e-12, atol=1e-15)
+    # the oracle (JacobiSVD restatement) and the LAPACK statement of the definition
+    dc.check_against_oracle(X, oracle.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp)
+    st = dc.check_definition(X, P0, P1, x, xp, err=e, what="batch")
+    assert st["well_separated"] > 99000
     oe = oracle.dlt_reprojection_error(P0, P1, x, xp)
-    assert np.allclose(e, oe, rtol=1e-9, atol=1e-12)
+    assert np.allclose(e, oe, rtol=1e-6, atol=1e-9)
 
 
 def test_device_path_10m_properties():
@@ -110,9 +129,15 @@ def test_score_hypotheses_matches_oracle(oracle):
     xp[::7] = rng.standard_normal((len(xp[::7]), 3))          # outliers
     P1s = np.stack(cams + [rng.standard_normal((3, 4)) for _ in range(3)])
     counts, mask = mvg.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2, return_mask=True)
-    ocounts, omask = oracle.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2)
-    assert np.array_equal(mask, omask)
-    assert np.array_equal(counts, ocounts) and np.array_equal(counts, mask.sum(1))
+    mcounts, mmask = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, 1e-2)
+    assert np.array_equal(mask, mmask)
+    assert np.array_equal(counts, mcounts) and np.array_equal(counts, mask.sum(1))
+    # the oracle (a JacobiSVD solve per point and hypothesis, src/RansacFitter.h:59-73): identical
+    # decisions except where its own error is within 1e-9 relative of the threshold
+    ocounts, omask, oerr = oracle.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2, return_err=True)
+    clear_o = np.abs(oerr - 1e-2) > 1e-11
+    assert np.array_equal(np.asarray(mask, bool)[clear_o], omask[clear_o])
+    assert np.all(np.abs(counts - ocounts) <= (~clear_o).sum(1))
     assert counts.argmax() == 0 and counts[0] > 0.8 * npt * 6 / 7
     assert np.array_equal(mvg.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2), counts)
     # the inlier definition, recomputed from the exported pieces
@@ -124,9 +149,11 @@ def test_score_hypotheses_matches_oracle(oracle):
     assert np.array_equal(mask[0][clear], ((err <= 1e-2) & front)[clear])
 
 
-def test_many_camera_pairs_bit_exact(oracle):
-    """30 random camera pairs (some nearly degenerate), noisy and noise-free points: the HIP kernel
-    and the oracle run the same explicit-FMA operation sequence, so they agree to the last bit."""
+def test_many_camera_pairs(oracle):
+    """30 random camera pairs (every fifth with almost no baseline, every seventh with a translation
+    column scaled by 1e4), noisy and noise-free points.  The HIP kernel reproduces the host mirror
+    of its operation sequence to the last bit, and -- the check that matters -- satisfies the
+    reference's definition (LAPACK) and agrees with the JacobiSVD oracle up to sign."""
     from spectavi_amd import mvg
     rng = np.random.default_rng(77)
     worst = 0.0
@@ -140,10 +167,11 @@ def test_many_camera_pairs_bit_exact(oracle):
         x = Xw @ P0.T + (k % 2) * rng.normal(0, 1e-3, (2003, 3))
         xp = Xw @ P1.T + (k % 2) * rng.normal(0, 1e-3, (2003, 3))
         X = mvg.dlt_triangulate(P0, P1, x, xp)
-        oX = oracle.dlt_triangulate(P0, P1, x, xp)
-        assert np.array_equal(np.isnan(X), np.isnan(oX))
-        worst = max(worst, float(np.nanmax(np.abs(X - oX))))
+        mX = oracle.dlt_mirror_triangulate(P0, P1, x, xp)
+        assert np.array_equal(np.isnan(X), np.isnan(mX))
+        worst = max(worst, float(np.nanmax(np.abs(X - mX))))
         e = mvg.dlt_reprojection_error(P0, P1, x, xp)
-        oe = oracle.dlt_reprojection_error(P0, P1, x, xp)
-        assert np.array_equal(e, oe, equal_nan=True)
+        assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp), equal_nan=True)
+        dc.check_definition(X, P0, P1, x, xp, err=e, what="pair %d" % k)
+        dc.check_against_oracle(X, oracle.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp, what="pair %d" % k)
     assert worst == 0.0

@@ -35,7 +35,7 @@ def test_l1k2_cascade_dlt_sharded(oracle, three_shards):
     P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
     Xw = rng.standard_normal((10007, 4))
     X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
-    assert np.max(np.abs(X - oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
+    assert np.max(np.abs(X - oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
     e = mvg.dlt_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T)
     assert e.shape == (10007, 1) and float(e.max()) < 1e-6
 
@@ -65,7 +65,7 @@ def test_concurrent_callers(oracle):
     P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
     Xw = rng.standard_normal((50000, 4))
     xa, xb = Xw @ P0.T, Xw @ P1.T  # once: a threaded BLAS need not reproduce its own bits
-    want_X = oracle.dlt_triangulate(P0, P1, xa, xb)
+    want_X = oracle.dlt_mirror_triangulate(P0, P1, xa, xb)
     errors = []
 
     def work(k):
@@ -124,7 +124,7 @@ def test_distributed_wrappers_single_rank_rccl(oracle):
         px, pxp = torch.from_numpy(Xw @ P0.T).to(dev), torch.from_numpy(Xw @ P1.T).to(dev)
         X = sharded.dlt_sharded(P0, P1, px, pxp, 501)
         E = sharded.dlt_sharded(P0, P1, px, pxp, 501, want_error=True)
-        assert np.max(np.abs(X.cpu().numpy() - oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
+        assert np.max(np.abs(X.cpu().numpy() - oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
         assert E.shape == (501, 1) and float(E.max()) < 1e-6
     finally:
         dist.destroy_process_group()

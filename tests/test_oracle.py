@@ -115,27 +115,128 @@ def test_cascade_candidates_closed_form(oracle, golden):
         assert idx[q].tolist() == want_i and dist[q].tolist() == want_d
 
 
+def _camera_pairs(seed=77, n=30, npt=2003):
+    """The camera pairs of tests/test_dlt_gpu.py::test_many_camera_pairs: random 3x4 pairs, every fifth
+    with almost no baseline, every seventh with a translation column scaled by 1e4; odd ones noisy."""
+    rng = np.random.default_rng(seed)
+    for k in range(n):
+        P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+        if k % 5 == 0:
+            P1 = P0 + 1e-6 * rng.standard_normal((3, 4))
+        if k % 7 == 0:
+            P0[:, 3] *= 1e4
+        Xw = rng.standard_normal((npt, 4))
+        x = Xw @ P0.T + (k % 2) * rng.normal(0, 1e-3, (npt, 3))
+        xp = Xw @ P1.T + (k % 2) * rng.normal(0, 1e-3, (npt, 3))
+        yield k, P0, P1, x, xp
+
+
+def test_jacobisvd_restatement_matches_lapack(oracle):
+    """oracle_jacobisvd.cpp (Eigen's two-sided JacobiSVD restated) against numpy.linalg.svd on 3x3
+    and 4x4 matrices incl. nearly singular, badly scaled, rank-deficient and zero ones."""
+    rng = np.random.default_rng(5)
+    for n in (3, 4):
+        for k in range(3000):
+            A = rng.standard_normal((n, n))
+            if k % 5 == 0:
+                A[:, 0] = A[:, 1] * (1 + 1e-9 * rng.standard_normal())
+            if k % 7 == 0:
+                A *= 10.0 ** rng.integers(-8, 9)
+            if k % 11 == 0:
+                A[n - 1] = 0
+            if k == 1:
+                A[:] = 0
+            U, S, V, sweeps = oracle.jacobisvd(A)
+            s = np.linalg.svd(A, compute_uv=False)
+            scale = max(s[0], 1e-300)
+            assert np.all(np.diff(S) <= 0) and np.all(S >= 0) and 1 <= sweeps <= 12
+            assert np.max(np.abs(S - s)) <= 1e-14 * scale
+            assert np.max(np.abs(U @ np.diag(S) @ V.T - A)) <= 1e-14 * scale
+            assert np.max(np.abs(U.T @ U - np.eye(n))) <= 1e-14 and np.max(np.abs(V.T @ V - np.eye(n))) <= 1e-14
+
+
 def test_dlt_reference_test_properties(oracle):
-    """reference test/test_mvg.py:94-125 on randn cameras and points."""
+    """reference test/test_mvg.py:94-125 on randn cameras and points, on the oracle (JacobiSVD
+    restatement) and on the host mirror of the HIP kernel's operation sequence."""
     rng = np.random.default_rng(0xdeadbeef)
     for _ in range(100):
         P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
         X0 = rng.standard_normal(4)
         x, xp = P0 @ X0, P1 @ X0
-        err = oracle.dlt_reprojection_error(P0, P1, x, xp)
-        assert abs(err[0, 0]) < 1e-3
-        X = oracle.dlt_triangulate(P0, P1, x, xp)[0]
-        assert np.allclose(X / X[3], X0 / X0[3])
-        assert np.allclose(np.cross(P0 @ X, x), 0, atol=1e-8)
-        assert abs(np.linalg.norm(X) - 1) < 1e-12 and X[3] >= 0
+        for tri, rep, canonical in ((oracle.dlt_triangulate, oracle.dlt_reprojection_error, False),
+                                    (oracle.dlt_mirror_triangulate, oracle.dlt_mirror_reprojection_error, True)):
+            err = rep(P0, P1, x, xp)
+            assert abs(err[0, 0]) < 1e-3
+            X = tri(P0, P1, x, xp)[0]
+            assert np.allclose(X / X[3], X0 / X0[3])
+            assert np.allclose(np.cross(P0 @ X, x), 0, atol=1e-8)
+            assert abs(np.linalg.norm(X) - 1) < 1e-12 and (X[3] >= 0 or not canonical)
 
 
 def test_dlt_matches_lapack_and_golden(oracle, golden):
     g = golden("dlt_1000.npz")
     X = oracle.dlt_triangulate(g["P0"], g["P1"], g["x"], g["xp"])
     assert np.array_equal(X, g["X"])
-    assert np.max(np.abs(X - g["X_lapack"])) < 1e-9
+    assert np.max(np.abs(oracle.canonical_sign(X) - g["X_lapack"])) < 1e-12
     err = oracle.dlt_reprojection_error(g["P0"], g["P1"], g["x"], g["xp"])
     assert np.array_equal(err, g["err"])
     assert np.all(err[:500] < 1e-9) and np.all(err[500:] < 1e-1)
     assert np.all(oracle.dlt_cheirality(g["P0"], g["P1"], g["x"], g["xp"]))
+    Xm = oracle.dlt_mirror_triangulate(g["P0"], g["P1"], g["x"], g["xp"])
+    assert np.array_equal(Xm, g["X_mirror"]) and np.max(np.abs(Xm - g["X_lapack"])) < 1e-12
+    assert np.array_equal(oracle.dlt_mirror_reprojection_error(g["P0"], g["P1"], g["x"], g["xp"]), g["err_mirror"])
+    assert np.all(oracle.dlt_mirror_cheirality(g["P0"], g["P1"], g["x"], g["xp"]))
+
+
+def test_dlt_definition_on_ill_conditioned_pairs(oracle):
+    """The reference's definition of X (smallest right singular vector of A, LAPACK as the solver,
+    tests/dlt_checks.py) on 30 camera pairs incl. near-zero baseline (sigma3 tiny) and 1e4-scaled
+    translations: for the oracle, and for the host mirror of the HIP fast path (Gram-Schmidt +
+    inverse iteration, no SVD), which the kernel reproduces bit for bit on the GPU."""
+    from tests import dlt_checks as dc
+    for k, P0, P1, x, xp in _camera_pairs():
+        oX = oracle.dlt_triangulate(P0, P1, x, xp)
+        dc.check_definition(oX, P0, P1, x, xp, err=oracle.dlt_reprojection_error(P0, P1, x, xp), what="oracle pair %d" % k,
+                            unfused=True)
+        mX = oracle.dlt_mirror_triangulate(P0, P1, x, xp)
+        dc.check_definition(mX, P0, P1, x, xp, err=oracle.dlt_mirror_reprojection_error(P0, P1, x, xp),
+                            what="mirror pair %d" % k)
+        dc.check_against_oracle(mX, oX, P0, P1, x, xp, what="mirror pair %d" % k)
+
+
+def test_dlt_scoring_mirror_agrees_with_oracle(oracle):
+    """RANSAC scoring (src/RansacFitter.h:59-73): the mirror's inlier decisions equal the oracle's
+    (JacobiSVD per point and hypothesis) except where the oracle's own reprojection error sits
+    within 1e-9 relative of the threshold."""
+    rng = np.random.default_rng(12)
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    R, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    t = rng.standard_normal((3, 1))
+    npt = 1500
+    Xw = np.hstack([rng.standard_normal((npt, 2)), rng.uniform(4, 8, (npt, 1)), np.ones((npt, 1))])
+    x, xp = Xw @ P0.T, Xw @ np.hstack([R, t]).T
+    xp[:, :2] += rng.normal(0, 2e-3, (npt, 2)) * xp[:, 2:3]
+    P1s = np.stack([np.hstack([R, t]), np.hstack([R, -t])] + [rng.standard_normal((3, 4)) for _ in range(6)])
+    for thr in (1e-3, 1e-2, 0.5):
+        oc, om, oe = oracle.dlt_score_hypotheses(P0, P1s, x, xp, thr, return_err=True)
+        mc, mm = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, thr)
+        clear = np.abs(oe - thr) > 1e-9 * thr
+        assert np.array_equal(om[clear], mm[clear])
+        assert np.all(np.abs(oc - mc) <= (~clear).sum(1))
+
+
+def test_dlt_fuzz_slice_on_the_mirror(oracle):
+    """The GPU fuzz's DLT and scoring cases (tests/fuzz_gpu.py: nearly identical cameras, points at
+    infinity, 1e6 homogeneous scale, inconsistent pairs, noise up to 10, inf/nan observations) with
+    the mirror standing in for the kernel it mirrors: definition (LAPACK) + oracle on every case."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(os.path.dirname(__file__), "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    try:
+        n = fz.fuzz_dlt(4, 4.0, impl=(oracle.dlt_mirror_triangulate, oracle.dlt_mirror_reprojection_error))
+        m = fz.fuzz_score(4, 3.0, impl=oracle.dlt_mirror_score_hypotheses)
+    except SystemExit as e:
+        pytest.fail(str(e))
+    assert n >= 20 and m >= 10
