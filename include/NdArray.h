@@ -20,6 +20,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -30,7 +33,8 @@ typedef struct NdArray {
   void *m_data;                      /* malloc'ed by ndarray_alloc, freed by ndarray_free */
   size_t m_shape[NDARRAY_MAX_DIMS];  /* row-major extents */
   int32_t m_ndim;                    /* number of valid extents */
-  int32_t m_itemsize;                /* bytes per element, set by the Python constructor */
+  int32_t m_itemsize;                /* bytes per element, set by the Python constructor
+                                        (byte offset 44 of this 48-byte struct on LP64) */
 } NdArray;
 
 /* C has no overloading: the 2-/3-extent forms used by the reference are
@@ -46,6 +50,9 @@ void ndarray_free(NdArray *arr);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 
 #endif /* SPECTAVI_AMD_NDARRAY_H */

@@ -21,7 +21,20 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* NdArray: the in-repo definition, or -- when libspectavi.so is built with
+ * `make NDARRAY_INC=/path/to/ctypes_ndarray/src` -- the reference's own <NdArray.h>
+ * (reference src/EigenDefinitions.h:22, CMakeLists.txt:26-27). */
+#ifdef SPECTAVI_EXTERNAL_NDARRAY
+#include <NdArray.h>
+#else
 #include "NdArray.h"
+#endif
+
+/* libspectavi.so is built with -fvisibility=hidden: only what is declared between this push and
+ * the matching pop is exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -52,6 +65,33 @@ int spv_set_device(int device);
  * replicated, and each shard is written straight into its slice of the caller's
  * output by a host thread per device; a device may be listed more than once. */
 int spv_set_devices(const int *devices, int count);
+/* How the shards of a multi-device host-pointer call reach the caller's arrays.
+ *   SPV_GATHER_RCCL   every device leaves its (idx0, idx1, d0, d1) records (16 bytes per query;
+ *                     DLT: its output rows) in HBM, one ncclCommInitAll clique (cached per device
+ *                     list) gathers them on the first listed device with ncclGather, one kernel
+ *                     widens them to the ABI layout, one copy brings them to the host -- the
+ *                     exchange step of SURVEY 8(e) for the loop the reference shards over OpenMP
+ *                     threads (src/BruteForceNnL1K2.h:92-93).  Works with a single device too
+ *                     (a clique of one).  Kernel names for spv_profile_read: "gather",
+ *                     "gather_widen".  librccl is opened on first use (SPECTAVI_RCCL_LIB overrides
+ *                     the name).
+ *   SPV_GATHER_DIRECT every shard is copied straight into its slice of the caller's arrays; no
+ *                     collective.
+ *   SPV_GATHER_AUTO   (default) environment SPECTAVI_GATHER = "rccl" | "direct" if set, else RCCL
+ *                     exactly when more than one distinct device is configured. */
+#define SPV_GATHER_AUTO (-1)
+#define SPV_GATHER_DIRECT 0
+#define SPV_GATHER_RCCL 1
+int spv_set_gather_mode(int mode);
+/* Host statement of the 16-byte record format (no GPU involved), for callers that run their own
+ * collective on raw records.  pack: idx uint64[n,2] ((size_t)-1 = no neighbour), dist32 = int32 or
+ * float32 [n,2] -> rec int32[n,4] = (idx0, idx1, d0 bits, d1 bits), -1 = no neighbour.
+ * unpack: rec [G][max_cnt][4] in rank order, ragged shards (contiguous balanced split of `total`
+ * rows, the first total % G shards one row longer) padded to max_cnt -> idx uint64[total,2],
+ * dist32 [total,2]. */
+int spv_records_pack(const uint64_t *idx, const void *dist32, long long n, int32_t *rec);
+int spv_records_unpack(const int32_t *rec, long long total, int G, long long max_cnt, uint64_t *idx,
+                       void *dist32);
 /* The host-pointer entry points keep freed device buffers in a per-device cache (up to
  * 4 GiB) for reuse by later calls; this releases them. */
 void spv_release_cached_memory(void);
@@ -244,6 +284,10 @@ int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int n
 
 #ifdef __cplusplus
 }
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 
 #endif /* SPECTAVI_AMD_H */

@@ -8,6 +8,6 @@ and DLT-triangulation hot path behind the reference's ctypes surface.
 Importing the package loads spectavi_amd/libspectavi.so (HIP); there is no CPU
 fallback (see spectavi_amd/_lib.py).
 """
-from spectavi_amd._lib import (SpectaviError, device_count, set_device, set_devices, set_hash_seed)  # noqa: F401
+from spectavi_amd._lib import (SpectaviError, device_count, set_device, set_devices, set_gather_mode, set_hash_seed)  # noqa: F401
 
 __version__ = "0.1.0"

@@ -99,3 +99,16 @@ def set_hash_seed(seed=None):
         clib.spv_set_hash_seed(0, 0)
     else:
         clib.spv_set_hash_seed(int(seed) & 0xFFFFFFFF, 1)
+
+
+GATHER_AUTO, GATHER_DIRECT, GATHER_RCCL = -1, 0, 1
+
+
+def set_gather_mode(mode):
+    """How multi-device host-array calls collect their shards: "rccl" (ncclGather of 16-byte records
+    on the first listed GPU, inside libspectavi.so), "direct" (each shard copied to its slice), or
+    "auto" (SPECTAVI_GATHER if set, else RCCL when more than one distinct device is listed)."""
+    mode = {"auto": GATHER_AUTO, "direct": GATHER_DIRECT, "rccl": GATHER_RCCL}.get(mode, mode)
+    clib.spv_set_gather_mode.restype = ct.c_int
+    clib.spv_set_gather_mode.argtypes = [ct.c_int]
+    check(clib.spv_set_gather_mode(int(mode)))

@@ -6,6 +6,7 @@
 // CPU fallback: every path ends in a HIP kernel launch or in an error status.
 
 #include "common.h"
+#include "records.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <exception>
 #include <initializer_list>
 #include <map>
+#include <memory>
 #include <new>
 #include <mutex>
 #include <string>
@@ -34,6 +36,7 @@ int g_device = -1;  // -1: not chosen yet
 std::vector<int> g_devices;  // empty: not chosen yet
 bool g_seed_fixed = false;
 uint32_t g_seed = 0;
+int g_gather_mode = -1;  // -1: SPECTAVI_GATHER, else automatic; SPV_GATHER_DIRECT / SPV_GATHER_RCCL
 }  // namespace
 
 int set_error(int status, const char *fmt, ...) {
@@ -70,7 +73,38 @@ static int guard(Fn fn) {
 namespace {
 std::mutex g_prof_mutex;
 std::atomic<bool> g_prof_on{false};
-std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> g_prof;
+// Per kernel name: running totals of the launches whose events have completed, and the event
+// pairs still in flight.  Completed pairs are folded into the totals (and their events destroyed)
+// whenever the pending list grows past kProfFoldAt, when profiling is switched off, and on every
+// read, so a long-running caller that leaves profiling enabled holds a bounded number of events.
+struct ProfEntry {
+  long long launches = 0;
+  double total_ms = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+std::map<std::string, ProfEntry> g_prof;
+constexpr size_t kProfFoldAt = 64;
+
+// g_prof_mutex held.  wait = true: block on every pending pair; false: fold only finished ones.
+void prof_fold(ProfEntry &e, bool wait) {
+  size_t keep = 0;
+  for (auto &ev : e.pending) {
+    const hipError_t q = wait ? hipEventSynchronize(ev.second) : hipEventQuery(ev.second);
+    if (q == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        e.total_ms += ms;
+        e.launches += 1;
+      }
+    } else if (q == hipErrorNotReady) {
+      e.pending[keep++] = ev;
+      continue;
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  e.pending.resize(keep);
+}
 }  // namespace
 
 ProfScope::ProfScope(const char *name, hipStream_t stream) : name_(name), stream_(stream) {
@@ -91,7 +125,31 @@ ProfScope::~ProfScope() {
   }
   (void)hipEventRecord(stop, stream_);
   std::lock_guard<std::mutex> lk(g_prof_mutex);
-  g_prof[name_].emplace_back(start_, stop);
+  ProfEntry &e = g_prof[name_];
+  e.pending.emplace_back(start_, stop);
+  if (e.pending.size() >= kProfFoldAt) prof_fold(e, false);
+}
+
+// The host-pointer entry points select their device(s) with hipSetDevice on the caller's thread
+// (and on their own shard threads).  The caller's current device is part of ITS state -- a
+// framework's tensors and streams hang off it -- so every such entry point restores it on exit.
+struct DeviceRestore {
+  int prev = -1;
+  DeviceRestore() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceRestore() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceRestore(const DeviceRestore &) = delete;
+  DeviceRestore &operator=(const DeviceRestore &) = delete;
+};
+
+// guard() for entry points that may switch the current device.
+template <typename Fn>
+static int host_guard(Fn fn) {
+  DeviceRestore restore;
+  return guard(fn);
 }
 
 static int use_device(int dev) {
@@ -138,6 +196,29 @@ static std::vector<int> device_list() {
   return g_devices;
 }
 
+// How the shards of a host-pointer call reach the caller's arrays: each shard copied straight
+// into its slice (direct), or gathered on the first listed GPU over RCCL and copied from there
+// (north_star's "RCCL gather of (idx0, idx1, d0, d1)").  spv_set_gather_mode / SPECTAVI_GATHER
+// choose; left alone, RCCL is used exactly when more than one distinct device is configured.
+static bool use_rccl_gather(const std::vector<int> &devs) {
+  int mode;
+  {
+    std::lock_guard<std::mutex> lk(g_cfg_mutex);
+    mode = g_gather_mode;
+  }
+  if (mode < 0) {
+    const char *e = getenv("SPECTAVI_GATHER");
+    if (e && !strcmp(e, "rccl")) mode = SPV_GATHER_RCCL;
+    if (e && !strcmp(e, "direct")) mode = SPV_GATHER_DIRECT;
+  }
+  if (mode >= 0) return mode == SPV_GATHER_RCCL;
+  if (devs.size() < 2) return false;
+  for (size_t a = 0; a < devs.size(); ++a)
+    for (size_t b = a + 1; b < devs.size(); ++b)
+      if (devs[a] == devs[b]) return false;  // a clique needs distinct devices
+  return true;
+}
+
 int ensure_device() { return use_device(device_list()[0]); }
 
 int device_cu_count() {
@@ -166,16 +247,24 @@ static int run_sharded(long long total, Fn fn) {
   std::vector<std::string> message(G);
   std::vector<std::thread> threads;
   const long long base = total / G, extra = total % G;
+  threads.reserve(G);
   for (int r = 0; r < G; ++r) {
     const long long lo = r * base + std::min<long long>(r, extra);
     const long long hi = lo + base + (r < extra ? 1 : 0);
-    threads.emplace_back([&, r, lo, hi] {
+    auto shard = [&, r, lo, hi] {
       status[r] = guard([&] {
         const int st = fn(devs[r], lo, hi);
         if (st != SPV_OK) message[r] = g_message;
         return st;
       });
-    });
+    };
+    // a thread that cannot be started (std::system_error) must not unwind through joinable
+    // threads (std::terminate): run that shard on this thread instead
+    try {
+      threads.emplace_back(shard);
+    } catch (...) {
+      shard();
+    }
   }
   for (auto &t : threads) t.join();
   for (int r = 0; r < G; ++r)
@@ -314,20 +403,20 @@ class HostPrefault {
   std::vector<std::thread> threads_;
 };
 
-#define SPV_TRY(expr)          \
-  do {                         \
-    int _s = (expr);           \
-    if (_s != SPV_OK) return _s; \
-  } while (0)
-
-int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
-                  uint64_t *idx, int32_t *dist) {
+int check_l1k2_args(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim, const uint64_t *idx,
+                    const int32_t *dist) {
   if (xrows < 0 || yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
   if (dim <= 0 || dim % 16 != 0)
     return set_error(SPV_ERR_INVALID,
                      "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
+  if (yrows > 0 && (!y || !idx || !dist || (xrows > 0 && !x))) return set_error(SPV_ERR_INVALID, "null pointer");
+  return SPV_OK;
+}
+
+int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
+                  uint64_t *idx, int32_t *dist) {
+  SPV_TRY(check_l1k2_args(x, y, xrows, yrows, dim, idx, dist));
   if (yrows == 0) return SPV_OK;
-  if (!y || !idx || !dist || (xrows > 0 && !x)) return set_error(SPV_ERR_INVALID, "null pointer");
   SPV_TRY(use_device(dev));
   const size_t xb = (size_t)xrows * dim, yb = (size_t)yrows * dim;
   const size_t wsb = spv_l1k2_workspace_bytes(xrows, yrows, dim);
@@ -354,9 +443,19 @@ int host_l1k2_one(int dev, const uint8_t *x, const uint8_t *y, int xrows, int yr
   return SPV_OK;
 }
 
+int host_l1k2_gathered(const std::vector<int> &devs, const uint8_t *x, const uint8_t *y, int xrows, int yrows,
+                       int dim, uint64_t *idx, int32_t *dist);
+int host_cascade_gathered(const std::vector<int> &devs, const float *x, const float *y, int xrows, int yrows,
+                          int dim, int m, int n, int g, const float *dict, uint64_t *idx, float *dist,
+                          int32_t *ncand);
+int host_dlt_gathered(const std::vector<int> &devs, const double *P0, const double *P1, int npt, const double *x,
+                      const double *xp, double *dst, bool want_error);
+
 int host_l1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim, uint64_t *idx,
               int32_t *dist) {
   if (yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
+  const std::vector<int> devs = device_list();
+  if (yrows > 0 && use_rccl_gather(devs)) return host_l1k2_gathered(devs, x, y, xrows, yrows, dim, idx, dist);
   return run_sharded(yrows, [&](int dev, long long lo, long long hi) {
     return host_l1k2_one(dev, x, y ? y + (size_t)lo * dim : y, xrows, (int)(hi - lo), dim,
                          idx ? idx + 2 * lo : idx, dist ? dist + 2 * lo : dist);
@@ -415,6 +514,9 @@ int host_cascade_one(int dev, const float *x, const float *y, int xrows, int yro
 int host_cascade(const float *x, const float *y, int xrows, int yrows, int dim, int m, int n,
                  int g, const float *dict, uint64_t *idx, float *dist, int32_t *ncand) {
   SPV_TRY(check_cascade_args(xrows, yrows, dim, m, n, g));
+  const std::vector<int> devs = device_list();
+  if (yrows > 0 && use_rccl_gather(devs))
+    return host_cascade_gathered(devs, x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand);
   return run_sharded(yrows, [&](int dev, long long lo, long long hi) {
     return host_cascade_one(dev, x, y ? y + (size_t)lo * dim : y, xrows, (int)(hi - lo), dim, m, n, g,
                             dict, idx ? idx + 2 * lo : idx, dist ? dist + 2 * lo : dist,
@@ -449,6 +551,8 @@ int host_dlt(const double *P0, const double *P1, int npt, const double *x, const
              double *dst, bool want_error) {
   if (npt < 0) return set_error(SPV_ERR_INVALID, "negative point count");
   const int cols = want_error ? 1 : 4;
+  const std::vector<int> devs = device_list();
+  if (npt > 0 && use_rccl_gather(devs)) return host_dlt_gathered(devs, P0, P1, npt, x, xp, dst, want_error);
   return run_sharded(npt, [&](int dev, long long lo, long long hi) {
     return host_dlt_one(dev, P0, P1, (int)(hi - lo), x ? x + 3 * lo : x, xp ? xp + 3 * lo : xp,
                         dst ? dst + cols * lo : dst, want_error);
@@ -552,6 +656,208 @@ int host_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *o
   return SPV_OK;
 }
 
+// ---- RCCL-gathered sharding -----------------------------------------------------------
+// Device buffers of one shard (or of the root), alive until every stream of the call has drained.
+struct BufList {
+  std::vector<std::unique_ptr<DevBuf>> v;
+  int add(size_t bytes, DevBuf **out) {
+    v.emplace_back(new DevBuf);
+    *out = v.back().get();
+    return (*out)->alloc(bytes);
+  }
+};
+
+// total rows over the listed devices: rank r runs `produce` on a host thread of its own (device
+// devs[r] current, work enqueued on the clique's stream r) and leaves its rows, row_bytes[k] each,
+// in K send buffers of max_cnt rows; the calling thread then gathers each of the K buffers on rank 0
+// with one ncclGather per rank (gather.hip) and runs `consume` on the root: recv[k] holds
+// [G][max_cnt] rows in rank order.  Everything is synchronised before the buffers are released.
+template <typename Produce, typename Consume>
+int run_gathered(const std::vector<int> &all_devs, long long total, const std::vector<size_t> &row_bytes,
+                 Produce produce, Consume consume) {
+  const int G = (int)std::min<long long>((long long)all_devs.size(), std::max<long long>(total, 1));
+  const std::vector<int> devs(all_devs.begin(), all_devs.begin() + G);
+  const size_t K = row_bytes.size();
+  std::lock_guard<std::mutex> lk(gather_mutex());  // one clique user at a time
+  for (int d : devs) SPV_TRY(use_device(d));         // fail early on a bad device number
+  GatherCtx *ctx = nullptr;
+  SPV_TRY(gather_ctx_get(devs, &ctx));
+  const long long max_cnt = shard_lo(total, G, 1);   // = size of shard 0, the largest
+  std::vector<BufList> bufs(G + 1);                  // [G] = the root's receive / staging buffers
+  std::vector<std::vector<const void *>> send(K, std::vector<const void *>(G, nullptr));
+  std::vector<int> status(G, SPV_OK);
+  std::vector<std::string> message(G);
+  {
+    std::vector<std::thread> threads;
+    threads.reserve(G);
+    for (int r = 0; r < G; ++r) {
+      auto shard = [&, r] {
+        status[r] = guard([&] {
+          int st = use_device(devs[r]);
+          if (st == SPV_OK) {
+            std::vector<const void *> mine(K, nullptr);
+            st = produce(r, shard_lo(total, G, r), shard_lo(total, G, r + 1), max_cnt, gather_stream(ctx, r),
+                         bufs[r], mine);
+            for (size_t k = 0; k < K; ++k) send[k][r] = mine[k];
+          }
+          if (st != SPV_OK) message[r] = g_message;
+          return st;
+        });
+      };
+      try {
+        threads.emplace_back(shard);
+      } catch (...) {
+        shard();
+      }
+    }
+    for (auto &t : threads) t.join();
+  }
+  int st = SPV_OK;
+  for (int r = 0; r < G && st == SPV_OK; ++r)
+    if (status[r] != SPV_OK) st = set_error(status[r], "device %d: %s", devs[r], message[r].c_str());
+  std::vector<const void *> recv(K, nullptr);
+  if (st == SPV_OK) st = use_device(devs[0]);
+  for (size_t k = 0; k < K && st == SPV_OK; ++k) {
+    DevBuf *rb = nullptr;
+    st = bufs[G].add((size_t)G * max_cnt * row_bytes[k], &rb);
+    if (st == SPV_OK) {
+      recv[k] = rb->p;
+      st = gather_bytes_run(ctx, send[k], rb->p, (size_t)max_cnt * row_bytes[k]);
+    }
+  }
+  if (st == SPV_OK) st = use_device(devs[0]);
+  if (st == SPV_OK) st = consume(recv, G, max_cnt, gather_stream(ctx, 0), bufs[G]);
+  // drain every rank's stream before its buffers go back to the pool, error or not
+  for (int r = 0; r < G; ++r)
+    if (hipSetDevice(devs[r]) == hipSuccess) {
+      const hipError_t e = hipStreamSynchronize(gather_stream(ctx, r));
+      if (e != hipSuccess && st == SPV_OK)
+        st = set_error(SPV_ERR_HIP, "device %d: %s", devs[r], hipGetErrorString(e));
+    }
+  return st;
+}
+
+int host_l1k2_gathered(const std::vector<int> &devs, const uint8_t *x, const uint8_t *y, int xrows, int yrows,
+                       int dim, uint64_t *idx, int32_t *dist) {
+  SPV_TRY(check_l1k2_args(x, y, xrows, yrows, dim, idx, dist));
+  const size_t xb = (size_t)xrows * dim;
+  HostPrefault touch_idx(idx, (size_t)yrows * 2 * sizeof(uint64_t), {{x, xb}, {y, (size_t)yrows * dim}});
+  auto produce = [&](int, long long lo, long long hi, long long max_cnt, hipStream_t st, BufList &b,
+                     std::vector<const void *> &send) {
+    const int cnt = (int)(hi - lo);
+    const size_t wsb = spv_l1k2_workspace_bytes(xrows, cnt, dim);
+    DevBuf *dx, *dy, *di, *dd, *ws, *rec;
+    SPV_TRY(b.add(xb, &dx));
+    SPV_TRY(b.add((size_t)cnt * dim, &dy));
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(uint64_t), &di));
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(int32_t), &dd));
+    SPV_TRY(b.add(wsb, &ws));
+    SPV_TRY(b.add((size_t)max_cnt * sizeof(Record), &rec));
+    if (xb) SPV_HIP_CHECK(hipMemcpyAsync(dx->p, x, xb, hipMemcpyHostToDevice, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dy->p, y + (size_t)lo * dim, (size_t)cnt * dim, hipMemcpyHostToDevice, st));
+    SPV_TRY(l1k2_run(dx->as<uint8_t>(), dy->as<uint8_t>(), xrows, cnt, dim, di->as<uint64_t>(), dd->as<int32_t>(),
+                     ws->p, wsb, st));
+    SPV_TRY(gather_pack_run(di->as<uint64_t>(), dd->p, cnt, rec->p, st));
+    send[0] = rec->p;
+    return SPV_OK;
+  };
+  auto consume = [&](const std::vector<const void *> &recv, int G, long long max_cnt, hipStream_t st, BufList &b) {
+    DevBuf *di, *dd;
+    SPV_TRY(b.add((size_t)yrows * 2 * sizeof(uint64_t), &di));
+    SPV_TRY(b.add((size_t)yrows * 2 * sizeof(int32_t), &dd));
+    SPV_TRY(gather_widen_run(recv[0], yrows, G, max_cnt, di->as<uint64_t>(), dd->p, st));
+    touch_idx.wait();
+    SPV_HIP_CHECK(hipMemcpyAsync(idx, di->p, (size_t)yrows * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dist, dd->p, (size_t)yrows * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    return SPV_OK;
+  };
+  return run_gathered(devs, yrows, {sizeof(Record)}, produce, consume);
+}
+
+int host_cascade_gathered(const std::vector<int> &devs, const float *x, const float *y, int xrows, int yrows,
+                          int dim, int m, int n, int g, const float *dict, uint64_t *idx, float *dist,
+                          int32_t *ncand) {
+  if (!y || !idx || !dist || !dict || (xrows > 0 && !x)) return set_error(SPV_ERR_INVALID, "null pointer");
+  const size_t xb = (size_t)xrows * dim * sizeof(float);
+  const size_t db = (size_t)n * dim * m * sizeof(float);
+  HostPrefault touch_idx(idx, (size_t)yrows * 2 * sizeof(uint64_t), {{x, xb}, {y, (size_t)yrows * dim * sizeof(float)}});
+  auto produce = [&](int, long long lo, long long hi, long long max_cnt, hipStream_t st, BufList &b,
+                     std::vector<const void *> &send) {
+    const int cnt = (int)(hi - lo);
+    const size_t yb = (size_t)cnt * dim * sizeof(float);
+    const size_t wsb = cascade_workspace_bytes(xrows, cnt, dim, m, n, g);
+    DevBuf *dx, *dy, *dd, *di, *dds, *dn, *ws, *rec;
+    SPV_TRY(b.add(xb, &dx));
+    SPV_TRY(b.add(yb, &dy));
+    SPV_TRY(b.add(db, &dd));
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(uint64_t), &di));
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(float), &dds));
+    SPV_TRY(b.add((size_t)max_cnt * sizeof(int32_t), &dn));
+    SPV_TRY(b.add(wsb, &ws));
+    SPV_TRY(b.add((size_t)max_cnt * sizeof(Record), &rec));
+    if (xb) SPV_HIP_CHECK(hipMemcpyAsync(dx->p, x, xb, hipMemcpyHostToDevice, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dy->p, y + (size_t)lo * dim, yb, hipMemcpyHostToDevice, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dd->p, dict, db, hipMemcpyHostToDevice, st));
+    SPV_TRY(cascade_run(dx->as<float>(), dy->as<float>(), xrows, cnt, dim, m, n, g, dd->as<float>(),
+                        di->as<uint64_t>(), dds->as<float>(), ncand ? dn->as<int32_t>() : nullptr, ws->p, wsb, st));
+    SPV_TRY(gather_pack_run(di->as<uint64_t>(), dds->p, cnt, rec->p, st));  // float32 distances as their bits
+    send[0] = rec->p;
+    if (ncand) send[1] = dn->p;
+    return SPV_OK;
+  };
+  auto consume = [&](const std::vector<const void *> &recv, int G, long long max_cnt, hipStream_t st, BufList &b) {
+    DevBuf *di, *dd;
+    SPV_TRY(b.add((size_t)yrows * 2 * sizeof(uint64_t), &di));
+    SPV_TRY(b.add((size_t)yrows * 2 * sizeof(float), &dd));
+    SPV_TRY(gather_widen_run(recv[0], yrows, G, max_cnt, di->as<uint64_t>(), dd->p, st));
+    touch_idx.wait();
+    SPV_HIP_CHECK(hipMemcpyAsync(idx, di->p, (size_t)yrows * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dist, dd->p, (size_t)yrows * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (ncand)
+      for (int r = 0; r < G; ++r) {  // 4 bytes per query: the shards' segments straight to their slices
+        const long long lo = shard_lo(yrows, G, r), hi = shard_lo(yrows, G, r + 1);
+        SPV_HIP_CHECK(hipMemcpyAsync(ncand + lo, static_cast<const int32_t *>(recv[1]) + (size_t)r * max_cnt,
+                                     (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      }
+    return SPV_OK;
+  };
+  std::vector<size_t> rows = {sizeof(Record)};
+  if (ncand) rows.push_back(sizeof(int32_t));
+  return run_gathered(devs, yrows, rows, produce, consume);
+}
+
+int host_dlt_gathered(const std::vector<int> &devs, const double *P0, const double *P1, int npt, const double *x,
+                      const double *xp, double *dst, bool want_error) {
+  if (!P0 || !P1 || !x || !xp || !dst) return set_error(SPV_ERR_INVALID, "null pointer");
+  const size_t row = (want_error ? 1 : 4) * sizeof(double);
+  HostPrefault touch(dst, (size_t)npt * row, {{x, (size_t)npt * 24}, {xp, (size_t)npt * 24}});
+  auto produce = [&](int, long long lo, long long hi, long long max_cnt, hipStream_t st, BufList &b,
+                     std::vector<const void *> &send) {
+    const long long cnt = hi - lo;
+    const size_t ib = (size_t)cnt * 3 * sizeof(double);
+    DevBuf *dx, *dxp, *dd;
+    SPV_TRY(b.add(ib, &dx));
+    SPV_TRY(b.add(ib, &dxp));
+    SPV_TRY(b.add((size_t)max_cnt * row, &dd));
+    SPV_HIP_CHECK(hipMemcpyAsync(dx->p, x + 3 * lo, ib, hipMemcpyHostToDevice, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dxp->p, xp + 3 * lo, ib, hipMemcpyHostToDevice, st));
+    SPV_TRY(dlt_run(P0, P1, cnt, dx->as<double>(), dxp->as<double>(), dd->as<double>(), want_error, st));
+    send[0] = dd->p;
+    return SPV_OK;
+  };
+  auto consume = [&](const std::vector<const void *> &recv, int G, long long max_cnt, hipStream_t st, BufList &) {
+    touch.wait();
+    for (int r = 0; r < G; ++r) {  // rows are already in the ABI layout: shard segments to their slices
+      const long long lo = shard_lo(npt, G, r), hi = shard_lo(npt, G, r + 1);
+      SPV_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(dst) + (size_t)lo * row,
+                                   static_cast<const char *>(recv[0]) + (size_t)r * max_cnt * row,
+                                   (size_t)(hi - lo) * row, hipMemcpyDeviceToHost, st));
+    }
+    return SPV_OK;
+  };
+  return run_gathered(devs, npt, {row}, produce, consume);
+}
+
 // Hyperplanes as the reference draws them (src/CascadingHashNn.h:86-100):
 // one std::mt19937 stream, std::normal_distribution<float>(0,1), table-major,
 // then dim (i), then bit (j).
@@ -562,12 +868,25 @@ void fill_hash_dict(uint32_t seed, int dim, int m, int n, float *dict) {
   for (size_t e = 0; e < total; ++e) dict[e] = normal(gen);
 }
 
+// The only place that touches NdArray members besides the callers' m_data reads.  With the in-repo
+// header (include/NdArray.h) the item size fixed by the Python constructor is cross-checked; when
+// built against the upstream ctypes_ndarray header (make NDARRAY_INC=...) define
+// SPV_NDARRAY_ITEMSIZE(arr) to its item-size member if it has one, else nothing is checked and the
+// upstream ndarray_alloc sizes the buffer as it always did for the reference.
+#if !defined(SPECTAVI_EXTERNAL_NDARRAY) && !defined(SPV_NDARRAY_ITEMSIZE)
+#define SPV_NDARRAY_ITEMSIZE(arr) ((arr)->m_itemsize)
+#endif
 int alloc_out(NdArray *arr, size_t rows, size_t cols, int itemsize) {
   if (!arr) return set_error(SPV_ERR_INVALID, "null NdArray");
-  if (arr->m_itemsize != itemsize)
-    return set_error(SPV_ERR_INVALID, "NdArray itemsize %d, expected %d", arr->m_itemsize, itemsize);
+#ifdef SPV_NDARRAY_ITEMSIZE
+  if ((int)SPV_NDARRAY_ITEMSIZE(arr) != itemsize)
+    return set_error(SPV_ERR_INVALID, "NdArray itemsize %d, expected %d", (int)SPV_NDARRAY_ITEMSIZE(arr), itemsize);
+#else
+  (void)itemsize;
+#endif
   ndarray_set_size(arr, rows, cols);
-  if (ndarray_alloc(arr) != 0) return set_error(SPV_ERR_NOMEM, "ndarray_alloc failed");
+  ndarray_alloc(arr);
+  if (!arr->m_data) return set_error(SPV_ERR_NOMEM, "ndarray_alloc failed");
   return SPV_OK;
 }
 
@@ -579,6 +898,10 @@ using namespace spv;
 extern "C" {
 
 // ---- NdArray ------------------------------------------------------------------------
+// In-repo implementation of the helpers the reference takes from its ctypes_ndarray submodule;
+// compiled out when the library is built against the upstream header and library
+// (make NDARRAY_INC=... NDARRAY_LIB=...), which then provide them.
+#ifndef SPECTAVI_EXTERNAL_NDARRAY
 void ndarray_set_size(NdArray *arr, size_t d0, size_t d1) {
   arr->m_ndim = 2;
   arr->m_shape[0] = d0;
@@ -605,6 +928,7 @@ void ndarray_free(NdArray *arr) {
     arr->m_data = nullptr;
   }
 }
+#endif  // !SPECTAVI_EXTERNAL_NDARRAY
 
 // ---- status -------------------------------------------------------------------------
 int spv_last_status(void) { return g_status; }
@@ -634,14 +958,29 @@ int spv_set_devices(const int *devices, int count) {
   return SPV_OK;
 }
 
+int spv_set_gather_mode(int mode) {
+  clear_error();
+  if (mode != SPV_GATHER_AUTO && mode != SPV_GATHER_DIRECT && mode != SPV_GATHER_RCCL)
+    return set_error(SPV_ERR_INVALID, "gather mode %d", mode);
+  std::lock_guard<std::mutex> lk(g_cfg_mutex);
+  g_gather_mode = mode;
+  return SPV_OK;
+}
+
 void spv_release_cached_memory(void) { g_pool.clear(); }
 
-void spv_profile_enable(int on) { g_prof_on.store(on != 0); }
+void spv_profile_enable(int on) {
+  g_prof_on.store(on != 0);
+  if (!on) {  // release the events of everything that has finished; totals stay readable
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    for (auto &kv : g_prof) prof_fold(kv.second, false);
+  }
+}
 
 void spv_profile_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mutex);
   for (auto &kv : g_prof)
-    for (auto &ev : kv.second) {
+    for (auto &ev : kv.second.pending) {
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
@@ -656,13 +995,9 @@ int spv_profile_read(const char *kernel, long long *launches, double *total_ms) 
   *total_ms = 0.0;
   auto it = g_prof.find(kernel);
   if (it == g_prof.end()) return SPV_OK;
-  for (auto &ev : it->second) {
-    SPV_HIP_CHECK(hipEventSynchronize(ev.second));
-    float ms = 0.f;
-    SPV_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
-    *total_ms += ms;
-    *launches += 1;
-  }
+  prof_fold(it->second, true);
+  *launches = it->second.launches;
+  *total_ms = it->second.total_ms;
   return SPV_OK;
 }
 
@@ -675,7 +1010,7 @@ void nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows,
     set_error(SPV_ERR_INVALID, "negative row count");
     return;
   }
-  (void)guard([&] {
+  (void)host_guard([&] {
     SPV_TRY(alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)));
     SPV_TRY(alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(int)));
     return host_l1k2(x, y, xrows, yrows, dim, static_cast<uint64_t *>(outidx->m_data),
@@ -691,7 +1026,7 @@ void nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int
     set_error(SPV_ERR_INVALID, "k=%d: only k=2 is defined (reference writes exactly two columns)", k);
     return;
   }
-  (void)guard([&] {
+  (void)host_guard([&] {
     SPV_TRY(check_cascade_args(xrows, yrows, dim, hash_bit_rate, num_hash_tables, num_candidate_neighbours));
     SPV_TRY(alloc_out(outidx, (size_t)yrows, 2, (int)sizeof(size_t)));
     SPV_TRY(alloc_out(outdist, (size_t)yrows, 2, (int)sizeof(float)));
@@ -717,27 +1052,27 @@ void nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int
 void dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                      const double *xp, double *dst) {
   clear_error();
-  (void)guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, false); });
+  (void)host_guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, false); });
 }
 
 void dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                             const double *xp, double *dst) {
   clear_error();
-  (void)guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, true); });
+  (void)host_guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, true); });
 }
 
 // ---- host-pointer status variants ---------------------------------------------------
 int spv_nn_bruteforcel1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
                           uint64_t *idx, int32_t *dist) {
   clear_error();
-  return guard([&] { return host_l1k2(x, y, xrows, yrows, dim, idx, dist); });
+  return host_guard([&] { return host_l1k2(x, y, xrows, yrows, dim, idx, dist); });
 }
 
 int spv_nn_cascading_hash(const float *x, const float *y, int xrows, int yrows, int dim, int m,
                           int n, int g, const float *dict, uint64_t *idx, float *dist,
                           int32_t *ncand) {
   clear_error();
-  return guard([&] { return host_cascade(x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand); });
+  return host_guard([&] { return host_cascade(x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand); });
 }
 
 int spv_generate_hash_dict(uint32_t seed, int dim, int m, int n, float *dict) {
@@ -756,11 +1091,11 @@ void spv_set_hash_seed(uint32_t seed, int use_fixed) {
 int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                         const double *xp, double *dst) {
   clear_error();
-  return guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, false); });
+  return host_guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, false); });
 }
 int spv_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8) {
   clear_error();
-  return guard([&] { return host_normalize(x, rows, dim, out_f32, out_u8); });
+  return host_guard([&] { return host_normalize(x, rows, dim, out_f32, out_u8); });
 }
 size_t spv_normalize_workspace_bytes(int dim) { return dim <= 0 ? 0 : normalize_workspace_bytes(dim); }
 int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, uint8_t *d_out_u8,
@@ -770,7 +1105,7 @@ int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, 
 }
 int spv_sift_split(const float *table, int rows, float *geom, uint8_t *desc) {
   clear_error();
-  return guard([&] { return host_sift_split(table, rows, geom, desc); });
+  return host_guard([&] { return host_sift_split(table, rows, geom, desc); });
 }
 int spv_sift_split_device(const float *d_table, int rows, float *d_geom, uint8_t *d_desc,
                           void *stream) {
@@ -787,7 +1122,7 @@ int spv_gather_match_coords_device(const float *d_geom_x, const float *d_geom_y,
 int spv_ratio_test(const uint64_t *idx, const void *dist, int dist_is_float, int yrows,
                    double min_ratio, int32_t *matches, int32_t *count) {
   clear_error();
-  return guard([&] { return host_ratio(idx, dist, dist_is_float, yrows, min_ratio, matches, count); });
+  return host_guard([&] { return host_ratio(idx, dist, dist_is_float, yrows, min_ratio, matches, count); });
 }
 size_t spv_ratio_test_workspace_bytes(int yrows) { return yrows < 0 ? 0 : ratio_workspace_bytes(yrows); }
 int spv_ratio_test_device(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int yrows,
@@ -801,7 +1136,7 @@ int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int 
                              const double *x, const double *xp, double max_error,
                              int32_t *counts, uint8_t *mask) {
   clear_error();
-  return guard([&] { return host_dlt_score(P0, P1s, nhyp, npt, x, xp, max_error, counts, mask); });
+  return host_guard([&] { return host_dlt_score(P0, P1s, nhyp, npt, x, xp, max_error, counts, mask); });
 }
 int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,
                                     long long npt, const double *d_x, const double *d_xp,
@@ -814,7 +1149,7 @@ int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int n
 int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                                const double *xp, double *dst) {
   clear_error();
-  return guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, true); });
+  return host_guard([&] { return host_dlt(P0, P1, npt, x, xp, dst, true); });
 }
 
 // ---- device-pointer variants --------------------------------------------------------

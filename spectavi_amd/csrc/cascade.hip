@@ -604,13 +604,12 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
     const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int m,
     int n, int g, int hb, const uint32_t *__restrict__ xcodes, const uint32_t *__restrict__ ysign,
     const uint32_t *__restrict__ ymask, const uint32_t *__restrict__ bstart,
-    const uint32_t *__restrict__ order, const uint8_t *__restrict__ only_flagged,
+    const uint32_t *__restrict__ order,
     uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
   __shared__ uint32_t lists[kThreads / 64][kListCap];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  // one query per wave; the driver loop at the end of the kernel serves both the full pass
-  // (grid = N/4 workgroups) and the overflow pass (flagged queries only)
+  // one query per wave
   auto process_query = [&](const int query) {
   uint32_t *list = lists[wave];
   const int sub = lane & 7;    // chunk owner inside the 8-lane group
@@ -758,20 +757,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
 
   const int nwaves = gridDim.x * (kThreads / 64);
   const int wave_id = blockIdx.x * (kThreads / 64) + wave;
-  if (only_flagged) {
-    // overflow pass: each wave scans 64 flags at a time and redoes only the flagged queries
-    for (int q0 = wave_id * 64; q0 < N; q0 += nwaves * 64) {
-      const bool f = q0 + lane < N && only_flagged[q0 + lane] != 0;
-      unsigned long long todo = __ballot(f);
-      while (todo) {
-        const int b = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        process_query(q0 + b);
-      }
-    }
-  } else {
-    for (int query = wave_id; query < N; query += nwaves) process_query(query);
-  }
+  for (int query = wave_id; query < N; query += nwaves) process_query(query);
 }
 
 
@@ -1050,6 +1036,18 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   if (!d_y || !d_dict || !d_idx || !d_dist || (xrows > 0 && !d_x))
     return set_error(SPV_ERR_INVALID, "null device pointer");
   if (g > 16) return set_error(SPV_ERR_INVALID, "num_candidate_neighbours g=%d > 16", g);
+  // before anything is enqueued: rows wider than the refine kernels take, misaligned bases
+  const int cpl = (dim / 16 + 7) / 8;
+  if (cpl > 16)
+    return set_error(SPV_ERR_INVALID, "dim=%d > 2048 is not supported by the cascade refine kernel",
+                     dim);
+  if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y) |
+       reinterpret_cast<uintptr_t>(d_dict) | reinterpret_cast<uintptr_t>(d_ws)) & 15)
+    return set_error(SPV_ERR_INVALID, "device pointers must be 16-byte aligned (x %p, y %p, dict %p, ws %p)",
+                     (const void *)d_x, (const void *)d_y, (const void *)d_dict, d_ws);
+  if ((reinterpret_cast<uintptr_t>(d_idx) & 7) || (reinterpret_cast<uintptr_t>(d_dist) & 3) ||
+      (reinterpret_cast<uintptr_t>(d_ncand) & 3))
+    return set_error(SPV_ERR_INVALID, "output pointers must be aligned to their element size");
   const CascadeLayout L = cascade_layout(xrows, yrows, dim, m, n);
   if (!d_ws || ws_bytes < L.total)
     return set_error(SPV_ERR_INVALID, "workspace too small: %zu < %zu", ws_bytes, L.total);
@@ -1105,10 +1103,6 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   SPV_HIP_CHECK(hipGetLastError());
 
   const dim3 grid((yrows + kThreads / 64 - 1) / (kThreads / 64)), block(kThreads);
-  const int cpl = (dim / 16 + 7) / 8;
-  if (cpl > 16)
-    return set_error(SPV_ERR_INVALID, "dim=%d > 2048 is not supported by the cascade refine kernel",
-                     dim);
   ProfScope prof_probe("cascade_probe_refine", stream);
   // group-per-query kernel unless the full-code check is needed (m > bucket bits) or rows
   // are wider than 256 bytes; otherwise the wave-per-query kernel
@@ -1129,10 +1123,9 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     return SPV_OK;
   }
   const dim3 pgrid(grid.x);
-  const uint8_t *flagged = nullptr;  // the kernel can restrict itself to flagged queries; unused now
 #define SPV_LAUNCH_PROBE(C, U)                                                                       \
   hipLaunchKernelGGL((probe_refine_kernel<C, U>), pgrid, block, 0, stream, ux, uy, xrows, yrows, dim, \
-                     m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, flagged, d_idx, d_dist,    \
+                     m, n, g, L.hb, xcodes, ysign, ymask, bstart, order, d_idx, d_dist,             \
                      d_ncand)
   static const int ru_env = [] {
     const char *e = getenv("SPECTAVI_CASCADE_RU");

@@ -6,6 +6,8 @@
 #include <stddef.h>
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "../../include/spectavi_amd.h"
 
@@ -23,6 +25,12 @@ void clear_error();
                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
                               __FILE__, __LINE__);                                       \
     }                                                                                    \
+  } while (0)
+
+#define SPV_TRY(expr)            \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != SPV_OK) return _s; \
   } while (0)
 
 // Selects the process-wide device for host-pointer entry points on this thread.
@@ -82,6 +90,20 @@ int gather_match_coords_run(const float *d_geom_x, const float *d_geom_y, const 
 size_t normalize_workspace_bytes(int dim);
 int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigned char *d_out_u8,
                   void *d_ws, size_t ws_bytes, hipStream_t stream);
+
+// ---- multi-device result gather over RCCL (gather.hip) -------------------------------
+struct GatherCtx;                    // communicator clique + one stream per rank, cached per device list
+std::mutex &gather_mutex();          // held by the caller around every use of a clique
+int gather_ctx_get(const std::vector<int> &devs, GatherCtx **out);
+hipStream_t gather_stream(GatherCtx *ctx, int rank);
+// (idx uint64[cnt,2], 32-bit dist[cnt,2]) -> cnt 16-byte records (records.h)
+int gather_pack_run(const uint64_t *d_idx, const void *d_d32, long long cnt, void *d_rec, hipStream_t stream);
+// ncclGather of bytes_per_rank bytes from every rank's d_send[r] into d_recv_root on rank 0
+int gather_bytes_run(GatherCtx *ctx, const std::vector<const void *> &d_send, void *d_recv_root,
+                     size_t bytes_per_rank);
+// [G][max_cnt] records -> the ABI layout over all `total` rows
+int gather_widen_run(const void *d_recv, long long total, int G, long long max_cnt, uint64_t *d_idx, void *d_d32,
+                     hipStream_t stream);
 
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,

@@ -267,87 +267,6 @@ __global__ __launch_bounds__(kThreads, 3) void l1k2_tile_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// Experimental scalar-feed variant (SPECTAVI_L1K2_FEED=sgpr): the database row is
-// fetched with wave-uniform scalar loads (s_load_dwordx8/x16 through the scalar
-// cache) and enters v_sad_hi_u8 as an SGPR operand; no LDS, no barriers.
-// ---------------------------------------------------------------------------------
-template <int D4, int Q>
-__device__ __forceinline__ void row_update_s(const uint32_t (&qreg)[Q][D4], const uint32_t (&xs)[D4],
-                                             uint32_t j, uint32_t (&k1)[Q], uint32_t (&k2)[Q]) {
-  uint32_t acc[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) acc[q] = j;
-#pragma unroll
-  for (int i = 0; i < D4; ++i) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = sad_hi(qreg[q][i], xs[i], acc[q]);
-  }
-#pragma unroll
-  for (int q = 0; q < Q; ++q) top2_insert(k1[q], k2[q], acc[q]);
-}
-
-template <int D4, int Q>
-__global__ __launch_bounds__(kThreads, 2) void l1k2_tile_kernel_sfeed(
-    const uint32_t *__restrict__ x, const uint4 *__restrict__ y, int M, int N, int slice_rows,
-    int S, uint64_t *__restrict__ part) {
-  constexpr int V4 = D4 / 4;
-  const int t = threadIdx.x;
-  const int qb = blockIdx.x;
-  const int s = blockIdx.y;
-  const int row_begin = s * slice_rows;
-  const int row_end = min(M, row_begin + slice_rows);
-
-  uint32_t qreg[Q][D4];
-  int qi[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    qi[q] = qb * (kThreads * Q) + q * kThreads + t;
-    const int src = min(qi[q], N - 1);
-    const uint4 *yr = y + (size_t)src * V4;
-#pragma unroll
-    for (int c = 0; c < V4; ++c) {
-      const uint4 v = yr[c];
-      qreg[q][4 * c + 0] = v.x;
-      qreg[q][4 * c + 1] = v.y;
-      qreg[q][4 * c + 2] = v.z;
-      qreg[q][4 * c + 3] = v.w;
-    }
-  }
-  uint32_t k1[Q], k2[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) k1[q] = k2[q] = kKeyNone;
-
-  const int nrows = row_end - row_begin;
-  if (nrows > 0) {
-    const uint32_t *xr = x + (size_t)row_begin * D4;
-    const uint32_t *xlast = x + (size_t)(row_end - 1) * D4;
-    uint32_t xa[D4], xb[D4];
-#pragma unroll
-    for (int i = 0; i < D4; ++i) xa[i] = xr[i];
-    for (int r = 0; r < nrows; r += 2) {
-      const uint32_t *x1 = (r + 1 < nrows) ? xr + D4 : xlast;
-#pragma unroll
-      for (int i = 0; i < D4; ++i) xb[i] = x1[i];
-      row_update_s<D4, Q>(qreg, xa, (uint32_t)r, k1, k2);
-      const uint32_t *x2 = (r + 2 < nrows) ? xr + 2 * D4 : xlast;
-#pragma unroll
-      for (int i = 0; i < D4; ++i) xa[i] = x2[i];
-      if (r + 1 < nrows) row_update_s<D4, Q>(qreg, xb, (uint32_t)(r + 1), k1, k2);
-      xr += 2 * D4;
-    }
-  }
-
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    if (qi[q] < N) {
-      uint64_t *dst = part + ((size_t)qi[q] * S + s) * 2;
-      dst[0] = widen_key(k1[q], (uint32_t)row_begin);
-      dst[1] = widen_key(k2[q], (uint32_t)row_begin);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // Generic-width fallback (256 < dim <= 2048): one wave per 64 queries, the queries live
 // transposed in LDS ([dim/4][64] dwords, conflict-free per-lane reads), database rows
 // arrive through wave-uniform scalar loads, 32-bit distance, 64-bit keys.  Correctness
@@ -452,32 +371,17 @@ __global__ __launch_bounds__(kThreads) void pad_rows_kernel(const uint8_t *__res
   }
 }
 
-// Experiment knobs (read once): SPECTAVI_L1K2_FEED=sgpr selects the scalar-feed
-// variant for dim 128; SPECTAVI_L1K2_Q / SPECTAVI_L1K2_BLOCKS override the plan.
+// Tuning knobs (read once): SPECTAVI_L1K2_Q / SPECTAVI_L1K2_BLOCKS override the plan
+// (tools/l1k2_sweep.py).
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
-}
-static bool use_sfeed() {
-  static const bool on = [] {
-    const char *v = getenv("SPECTAVI_L1K2_FEED");
-    return v && v[0] == 's';
-  }();
-  return on;
 }
 
 template <int D4, int Q>
 void launch_tile(const uint8_t *x, const uint8_t *y, int M, int N, const L1K2Plan &p,
                  uint64_t *part, hipStream_t stream) {
   dim3 grid(p.qblocks, p.slices);
-  if constexpr (D4 == 32) {
-    if (use_sfeed()) {
-      hipLaunchKernelGGL((l1k2_tile_kernel_sfeed<D4, Q>), grid, dim3(kThreads), 0, stream,
-                         reinterpret_cast<const uint32_t *>(x),
-                         reinterpret_cast<const uint4 *>(y), M, N, p.slice_rows, p.slices, part);
-      return;
-    }
-  }
   hipLaunchKernelGGL((l1k2_tile_kernel<D4, Q>), grid, dim3(kThreads), 0, stream,
                      reinterpret_cast<const uint4 *>(x), reinterpret_cast<const uint4 *>(y), M, N,
                      p.slice_rows, p.slices, part);
@@ -563,6 +467,14 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
   if (yrows == 0) return SPV_OK;
   if (!d_y || !d_idx || !d_dist || (xrows > 0 && !d_x))
     return set_error(SPV_ERR_INVALID, "null device pointer");
+  // the kernels read rows as 16-byte vectors (the reference's sad_16 needs the same alignment:
+  // _mm_load_si128, src/BruteForceNnL1K2.h:43-48) and write 8- / 4-byte results
+  if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y) |
+       reinterpret_cast<uintptr_t>(d_ws)) & 15)
+    return set_error(SPV_ERR_INVALID, "device pointers must be 16-byte aligned (x %p, y %p, ws %p)",
+                     (const void *)d_x, (const void *)d_y, d_ws);
+  if ((reinterpret_cast<uintptr_t>(d_idx) & 7) || (reinterpret_cast<uintptr_t>(d_dist) & 3))
+    return set_error(SPV_ERR_INVALID, "output pointers must be aligned to their element size");
   const L1K2Plan p = l1k2_plan(xrows, yrows, dim);
   if (ws_bytes < p.total_bytes || !d_ws)
     return set_error(SPV_ERR_INVALID, "workspace too small: %zu < %zu", ws_bytes, p.total_bytes);

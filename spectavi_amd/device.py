@@ -36,8 +36,29 @@ clib.spv_profile_reset.restype = None
 clib.spv_profile_reset.argtypes = []
 
 
-def _stream():
-    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(dev=None):
+    return ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _on_device_of:
+    """All tensors of one call must live on ONE GPU; the call then runs with that GPU as the current
+    device and on torch's current stream OF THAT GPU, whatever the process-wide current device is
+    (the library launches on the calling thread's current HIP device), and the previous device is
+    restored afterwards."""
+
+    def __init__(self, *tensors):
+        devs = {t.device for t in tensors if t is not None}
+        if len(devs) != 1:
+            raise ValueError("all tensors of one call must live on the same GPU, got %s" % sorted(map(str, devs)))
+        self.device = devs.pop()
+        self._ctx = torch.cuda.device(self.device)
+
+    def __enter__(self):
+        self._ctx.__enter__()
+        return _stream(self.device)
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
 
 
 def _need(t, dtype, name):
@@ -75,9 +96,10 @@ def l1k2(x, y, workspace=None):
     idx = torch.empty((yrows, 2), dtype=torch.int64, device=y.device)
     dist = torch.empty((yrows, 2), dtype=torch.int32, device=y.device)
     nbytes = clib.spv_l1k2_workspace_bytes(xrows, yrows, dim)
-    ws = (workspace or _default_ws).get(nbytes, y.device)
-    check(clib.spv_l1k2_device(x.data_ptr(), y.data_ptr(), xrows, yrows, dim, idx.data_ptr(),
-                               dist.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    with _on_device_of(x, y) as stream:
+        ws = (workspace or _default_ws).get(nbytes, y.device)
+        check(clib.spv_l1k2_device(x.data_ptr(), y.data_ptr(), xrows, yrows, dim, idx.data_ptr(),
+                                   dist.data_ptr(), ws.data_ptr(), ws.numel(), stream))
     return idx, dist
 
 
@@ -94,11 +116,12 @@ def cascade(x, y, hash_dict, g=2, workspace=None, want_ncand=False):
     dist = torch.empty((yrows, 2), dtype=torch.float32, device=y.device)
     ncand = torch.empty((yrows,), dtype=torch.int32, device=y.device) if want_ncand else None
     nbytes = clib.spv_cascade_workspace_bytes(xrows, yrows, dim, m, n, g)
-    ws = (workspace or _default_ws).get(nbytes, y.device)
-    check(clib.spv_cascade_device(x.data_ptr(), y.data_ptr(), xrows, yrows, dim, m, n, g,
-                                  hash_dict.data_ptr(), idx.data_ptr(), dist.data_ptr(),
-                                  ncand.data_ptr() if want_ncand else None, ws.data_ptr(),
-                                  ws.numel(), _stream()))
+    with _on_device_of(x, y, hash_dict) as stream:
+        ws = (workspace or _default_ws).get(nbytes, y.device)
+        check(clib.spv_cascade_device(x.data_ptr(), y.data_ptr(), xrows, yrows, dim, m, n, g,
+                                      hash_dict.data_ptr(), idx.data_ptr(), dist.data_ptr(),
+                                      ncand.data_ptr() if want_ncand else None, ws.data_ptr(),
+                                      ws.numel(), stream))
     return (idx, dist, ncand) if want_ncand else (idx, dist)
 
 
@@ -111,7 +134,8 @@ def _dlt(fn, P0, P1, x, xp, cols):
     assert P0.shape == (3, 4) and P1.shape == (3, 4)
     npt = x.shape[0]
     dst = torch.empty((npt, cols), dtype=torch.float64, device=x.device)
-    check(fn(P0, P1, npt, x.data_ptr(), xp.data_ptr(), dst.data_ptr(), _stream()))
+    with _on_device_of(x, xp) as stream:
+        check(fn(P0, P1, npt, x.data_ptr(), xp.data_ptr(), dst.data_ptr(), stream))
     return dst
 
 
@@ -146,10 +170,11 @@ def ratio_test(idx, dist, min_ratio, workspace=None):
     n = idx.shape[0]
     matches = torch.empty((n, 2), dtype=torch.int32, device=idx.device)
     count = torch.zeros((1,), dtype=torch.int32, device=idx.device)
-    ws = (workspace or _default_ws).get(clib.spv_ratio_test_workspace_bytes(n), idx.device)
-    check(clib.spv_ratio_test_device(idx.data_ptr(), dist.data_ptr(), is_float, n, float(min_ratio),
-                                     matches.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     _stream()))
+    with _on_device_of(idx, dist) as stream:
+        ws = (workspace or _default_ws).get(clib.spv_ratio_test_workspace_bytes(n), idx.device)
+        check(clib.spv_ratio_test_device(idx.data_ptr(), dist.data_ptr(), is_float, n, float(min_ratio),
+                                         matches.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         stream))
     return matches, count
 
 
@@ -163,9 +188,10 @@ def dlt_score_hypotheses(P0, P1s, x, xp, max_error, want_mask=False):
     nh, npt = P1s.shape[0], x.shape[0]
     counts = torch.empty((nh,), dtype=torch.int32, device=x.device)
     mask = torch.empty((nh, npt), dtype=torch.uint8, device=x.device) if want_mask else None
-    check(clib.spv_dlt_score_hypotheses_device(P0, P1s.data_ptr(), nh, npt, x.data_ptr(), xp.data_ptr(),
-                                               float(max_error), counts.data_ptr(),
-                                               mask.data_ptr() if want_mask else None, _stream()))
+    with _on_device_of(P1s, x, xp) as stream:
+        check(clib.spv_dlt_score_hypotheses_device(P0, P1s.data_ptr(), nh, npt, x.data_ptr(), xp.data_ptr(),
+                                                   float(max_error), counts.data_ptr(),
+                                                   mask.data_ptr() if want_mask else None, stream))
     return (counts, mask) if want_mask else counts
 
 
@@ -182,7 +208,8 @@ def split_sift_table(table):
     n = table.shape[0]
     geom = torch.empty((n, 4), dtype=torch.float32, device=table.device)
     desc = torch.empty((n, 128), dtype=torch.uint8, device=table.device)
-    check(clib.spv_sift_split_device(table.data_ptr(), n, geom.data_ptr(), desc.data_ptr(), _stream()))
+    with _on_device_of(table) as stream:
+        check(clib.spv_sift_split_device(table.data_ptr(), n, geom.data_ptr(), desc.data_ptr(), stream))
     return geom, desc
 
 
@@ -195,8 +222,9 @@ def match_coordinates(geom_x, geom_y, matches, count):
     cap = matches.shape[0]
     x0 = torch.zeros((cap, 3), dtype=torch.float64, device=matches.device)
     x1 = torch.zeros((cap, 3), dtype=torch.float64, device=matches.device)
-    check(clib.spv_gather_match_coords_device(geom_x.data_ptr(), geom_y.data_ptr(), matches.data_ptr(),
-                                              count.data_ptr(), cap, x0.data_ptr(), x1.data_ptr(), _stream()))
+    with _on_device_of(geom_x, geom_y, matches, count) as stream:
+        check(clib.spv_gather_match_coords_device(geom_x.data_ptr(), geom_y.data_ptr(), matches.data_ptr(),
+                                                  count.data_ptr(), cap, x0.data_ptr(), x1.data_ptr(), stream))
     return x0, x1
 
 

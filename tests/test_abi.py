@@ -154,3 +154,79 @@ def test_frontend_signatures_match_reference_source():
     assert len(feature._nn_cascading_hash.argtypes) == ref_argtypes_len(ftree, "_nn_cascading_hash") == 11
     assert len(mvg._dlt_triangulate.argtypes) == ref_argtypes_len(mtree, "_dlt_triangulate") == 6
     assert len(mvg._dlt_reprojection_error.argtypes) == ref_argtypes_len(mtree, "_dlt_reprojection_error") == 6
+
+
+def test_only_the_declared_api_is_exported():
+    """libspectavi.so is built -fvisibility=hidden: its dynamic symbol table holds the declared
+    extern "C" API and nothing else of its own (no C++ internals another library could interpose)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "spectavi_amd", "libspectavi.so")],
+                         capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
+
+
+def test_record_pack_and_widen_arithmetic():
+    """The 16-byte (idx0, idx1, d0, d1) record that the RCCL gather moves (spectavi_amd/csrc/records.h,
+    the same inline functions the device kernels call): (size_t)-1 travels as -1 and comes back as
+    (size_t)-1, indices up to 2^31-1 and both distance types survive bit for bit, ragged shards map
+    back to their rows.  Host functions only; no GPU involved."""
+    from spectavi_amd._lib import clib, SPV_ERR_INVALID
+    u64p, i32p = ct.POINTER(ct.c_uint64), ct.POINTER(ct.c_int32)
+    clib.spv_records_pack.restype = ct.c_int
+    clib.spv_records_pack.argtypes = [u64p, ct.c_void_p, ct.c_longlong, i32p]
+    clib.spv_records_unpack.restype = ct.c_int
+    clib.spv_records_unpack.argtypes = [i32p, ct.c_longlong, ct.c_int, ct.c_longlong, u64p, ct.c_void_p]
+    rng = np.random.default_rng(9)
+    none = np.iinfo(np.uint64).max
+    for total, G in ((1, 1), (7, 1), (7, 3), (8, 8), (1001, 3), (1000, 8), (5, 4), (64, 7)):
+        idx = rng.integers(0, 2**31, (total, 2)).astype(np.uint64)
+        idx[0, 0] = 2**31 - 1
+        idx[rng.random(total) < 0.2, 1] = none               # one neighbour only
+        idx[rng.random(total) < 0.1] = none                  # none at all
+        for dist in (rng.integers(0, 2**31, (total, 2)).astype(np.int32),
+                     rng.standard_normal((total, 2)).astype(np.float32)):
+            dist[idx == none] = 2147483647 if dist.dtype == np.int32 else 2147483648.0
+            # what each rank would pack from its contiguous shard, padded to the largest shard
+            base, extra = divmod(total, G)
+            max_cnt = base + (1 if extra else 0)
+            rec = np.full((G, max_cnt, 4), 0x5A5A5A5A, np.int32)
+            lo = 0
+            for r in range(G):
+                cnt = base + (1 if r < extra else 0)
+                part_i = np.ascontiguousarray(idx[lo:lo + cnt])
+                part_d = np.ascontiguousarray(dist[lo:lo + cnt])
+                out = np.empty((cnt, 4), np.int32)
+                assert clib.spv_records_pack(part_i.ctypes.data_as(u64p), part_d.ctypes.data, cnt,
+                                             out.ctypes.data_as(i32p)) == 0
+                assert np.array_equal(out[:, :2] == -1, part_i == none)
+                assert np.array_equal(out[:, 2:].view(dist.dtype), part_d)
+                rec[r, :cnt] = out
+                lo += cnt
+            gi, gd = np.empty((total, 2), np.uint64), np.empty((total, 2), dist.dtype)
+            assert clib.spv_records_unpack(rec.ctypes.data_as(i32p), total, G, max_cnt, gi.ctypes.data_as(u64p),
+                                           gd.ctypes.data) == 0
+            assert np.array_equal(gi, idx) and np.array_equal(gd.view(np.uint32), dist.view(np.uint32))
+    # python statement of the same record (sharded.py) agrees
+    import torch
+    from spectavi_amd.sharded import pack_records, unpack_records
+    idx = np.array([[5, none], [none, none], [2**31 - 1, 0]], np.uint64)
+    dist = np.array([[7, 2147483647], [2147483647, 2147483647], [0, 65280]], np.int32)
+    rec = np.empty((3, 4), np.int32)
+    clib.spv_records_pack(idx.ctypes.data_as(u64p), dist.ctypes.data, 3, rec.ctypes.data_as(i32p))
+    trec = pack_records(torch.from_numpy(idx.view(np.int64)), torch.from_numpy(dist))
+    assert np.array_equal(trec.numpy(), rec)
+    ti, td = unpack_records(trec)
+    assert np.array_equal(ti.numpy().view(np.uint64), idx) and np.array_equal(td.numpy(), dist)
+    # a max_cnt smaller than the largest shard is refused
+    assert clib.spv_records_unpack(rec.ctypes.data_as(i32p), 3, 2, 1, idx.ctypes.data_as(u64p),
+                                   dist.ctypes.data) == SPV_ERR_INVALID
+
+
+def test_gather_mode_api_without_gpu():
+    from spectavi_amd._lib import clib, SPV_ERR_INVALID
+    clib.spv_set_gather_mode.restype = ct.c_int
+    clib.spv_set_gather_mode.argtypes = [ct.c_int]
+    assert clib.spv_set_gather_mode(7) == SPV_ERR_INVALID
+    for mode in (1, 0, -1):
+        assert clib.spv_set_gather_mode(mode) == 0

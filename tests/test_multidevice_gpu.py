@@ -128,3 +128,119 @@ def test_distributed_wrappers_single_rank_rccl(oracle):
         assert E.shape == (501, 1) and float(E.max()) < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+@pytest.fixture
+def rccl_gather():
+    """Force the in-library RCCL gather for a clique of one (this box has one GPU): the shards'
+    16-byte records are packed on the device, gathered with ncclGather on the root, widened by the
+    root's kernel and copied out once -- the code path that runs unchanged over 8 GPUs."""
+    import spectavi_amd
+    spectavi_amd.set_devices([0])
+    spectavi_amd.set_gather_mode("rccl")
+    yield
+    spectavi_amd.set_gather_mode("auto")
+
+
+def test_in_library_rccl_gather_clique_of_one(oracle, rccl_gather):
+    """nn_bruteforcel1k2, nn_cascading_hash, dlt_triangulate and dlt_reprojection_error through the
+    unchanged reference-style front-end with SPV_GATHER_RCCL: results identical to the oracle, the
+    collective really ran (spv_profile_read("gather") counts launches), sentinels survive the
+    32-bit records, and no PyTorch is involved in the exchange."""
+    from spectavi_amd import device, feature, mvg
+    device.profile_reset()
+    device.profile_enable(True)
+    rng = np.random.default_rng(2026)
+    x = rng.integers(0, 256, (3000, 128), dtype=np.uint8)
+    y = rng.integers(0, 256, (1001, 128), dtype=np.uint8)
+    idx, dist = feature.nn_bruteforcel1k2(x, y)
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    # fewer than two database rows: (size_t)-1 / INT_MAX travel through the records as -1
+    idx1, dist1 = feature.nn_bruteforcel1k2(x[:1], y[:5])
+    oidx1, odist1 = oracle.nn_bruteforcel1k2(x[:1], y[:5])
+    assert np.array_equal(idx1, oidx1) and np.array_equal(dist1, odist1)
+    assert idx1[0, 1] == np.iinfo(np.uint64).max and dist1[0, 1] == np.iinfo(np.int32).max
+
+    xf, yf = x.astype(np.float32) - 128, y.astype(np.float32) - 128
+    d = rng.standard_normal((2, 128, 8)).astype(np.float32)
+    cidx, cdist, ncand = feature.nn_cascading_hash_with_dict(xf, yf, d, g=2, return_ncand=True)
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(xf, yf, 8, 2, 2, d)
+    assert np.array_equal(cidx, oidx) and np.array_equal(cdist, odist) and np.array_equal(ncand, oncand)
+
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((10007, 4))
+    X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert np.array_equal(X, oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))
+    oX = oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert np.max(np.abs(X - np.sign(np.einsum("ni,ni->n", X, oX))[:, None] * oX)) < 1e-9
+    e = mvg.dlt_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert e.shape == (10007, 1) and np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T))
+    device.profile_enable(False)
+    launches, ms = device.profile_read("gather")
+    assert launches == 6 and ms > 0.0          # 2 x L1 + cascade records + cascade ncand + 2 x DLT
+    assert device.profile_read("gather_widen")[0] == 3
+
+
+def test_rccl_gather_rejects_a_device_listed_twice(rccl_gather):
+    import spectavi_amd
+    from spectavi_amd import feature
+    spectavi_amd.set_devices([0, 0])
+    try:
+        with pytest.raises(spectavi_amd.SpectaviError, match="listed twice"):
+            feature.nn_bruteforcel1k2(np.zeros((8, 16), np.uint8), np.zeros((8, 16), np.uint8))
+    finally:
+        spectavi_amd.set_devices([0])
+
+
+def test_misaligned_device_pointers_are_rejected():
+    """spv_l1k2_device / spv_cascade_device read rows as 16-byte vectors: a tensor view that starts
+    off a 16-byte boundary must come back as SPV_ERR_INVALID, not as a fault."""
+    import torch
+    from spectavi_amd._lib import clib, SPV_ERR_INVALID
+    from spectavi_amd import device  # noqa: F401  (declares argtypes)
+    buf = torch.zeros(1000 * 128 + 64, dtype=torch.uint8, device="cuda")
+    x = buf[:1000 * 128]
+    idx = torch.empty((1000, 2), dtype=torch.int64, device="cuda")
+    dist = torch.empty((1000, 2), dtype=torch.int32, device="cuda")
+    n = clib.spv_l1k2_workspace_bytes(1000, 1000, 128)
+    ws = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    ok = clib.spv_l1k2_device(x.data_ptr(), x.data_ptr(), 1000, 1000, 128, idx.data_ptr(), dist.data_ptr(),
+                              ws.data_ptr(), n, None)
+    assert ok == 0
+    for dx, dy, dw in ((4, 0, 0), (0, 8, 0), (0, 0, 4)):
+        st = clib.spv_l1k2_device(x.data_ptr() + dx, x.data_ptr() + dy, 1000, 1000, 128, idx.data_ptr(),
+                                  dist.data_ptr(), ws.data_ptr() + dw, n, None)
+        assert st == SPV_ERR_INVALID and b"16-byte aligned" in clib.spv_last_error()
+    st = clib.spv_l1k2_device(x.data_ptr(), x.data_ptr(), 1000, 1000, 128, idx.data_ptr() + 4, dist.data_ptr(),
+                              ws.data_ptr(), n, None)
+    assert st == SPV_ERR_INVALID
+    xf = torch.zeros(200 * 128 + 16, dtype=torch.float32, device="cuda")
+    hd = torch.zeros(2 * 128 * 6 + 4, dtype=torch.float32, device="cuda")
+    cn = clib.spv_cascade_workspace_bytes(200, 200, 128, 6, 2, 2)
+    cws = torch.empty(cn, dtype=torch.uint8, device="cuda")
+    fd = torch.empty((200, 2), dtype=torch.float32, device="cuda")
+    for off_x, off_d in ((4, 0), (0, 4)):
+        st = clib.spv_cascade_device(xf.data_ptr() + off_x, xf.data_ptr(), 200, 200, 128, 6, 2, 2, hd.data_ptr() + off_d,
+                                     idx.data_ptr(), fd.data_ptr(), None, cws.data_ptr(), cn, None)
+        assert st == SPV_ERR_INVALID and b"16-byte aligned" in clib.spv_last_error()
+    # rows wider than the refine kernels take are refused before anything is enqueued
+    st = clib.spv_cascade_device(xf.data_ptr(), xf.data_ptr(), 2, 2, 2064, 6, 2, 2, hd.data_ptr(), idx.data_ptr(),
+                                 fd.data_ptr(), None, cws.data_ptr(), cn, None)
+    assert st == SPV_ERR_INVALID and b"2048" in clib.spv_last_error()
+
+
+def test_host_entry_points_restore_the_callers_device():
+    """A host-array call selects its device(s) with hipSetDevice; the caller's current device --
+    torch's, here -- must be what it was when the call returns (with one GPU: still device 0, and
+    the call must not have been confused by a caller stream / device context either)."""
+    import torch
+    from spectavi_amd import feature
+    torch.cuda.set_device(0)
+    before = torch.cuda.current_device()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        feature.nn_bruteforcel1k2(np.zeros((64, 16), np.uint8), np.ones((8, 16), np.uint8))
+    assert torch.cuda.current_device() == before
+    t = torch.ones(4, device="cuda") * 2            # torch still works on its device afterwards
+    assert float(t.sum()) == 8.0

@@ -28,11 +28,11 @@ print(json.dumps({"ms": ms / k, "pairs_per_s": float(n) * n / (ms / k * 1e-3)}))
 
 def main():
     rows = []
-    feeds = os.environ.get("SWEEP_FEEDS", "lds,sgpr").split(",")
+    feeds = ["lds"]  # the scalar-feed variant left the library (tools/exp/l1k2_sfeed_exp.hip)
     qs = [int(v) for v in os.environ.get("SWEEP_QS", "1,2,4").split(",")]
     blks = [int(v) for v in os.environ.get("SWEEP_BLOCKS", "1024,2048,4096").split(",")]
     for feed, q, blocks in itertools.product(feeds, qs, blks):
-        env = dict(os.environ, SPECTAVI_L1K2_FEED=feed, SPECTAVI_L1K2_Q=str(q), SPECTAVI_L1K2_BLOCKS=str(blocks))
+        env = dict(os.environ, SPECTAVI_L1K2_Q=str(q), SPECTAVI_L1K2_BLOCKS=str(blocks))
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]
         try:
