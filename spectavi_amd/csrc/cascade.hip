@@ -282,110 +282,34 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
 // through LDS so that one lane holds one row's n*m projections and runs the same epilogue as
 // the VALU kernel: sign codes, the g least-confident bits, bucket histogram.
 // ---------------------------------------------------------------------------------
+constexpr int kMfmaChunkC = 32;  // = kMfmaChunk (declared below): dims per step of the MFMA kernels
 __global__ void repack_dict_mfma_kernel(const float *__restrict__ dict, float *__restrict__ dictm, int n,
                                         int dim, int m, int nc) {
-  const int total = dim * nc;
+  const int dimpad = (dim + kMfmaChunkC - 1) / kMfmaChunkC * kMfmaChunkC;  // whole chunks: zero rows past dim
+  const int total = dimpad * nc;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int c = e % nc, i = e / nc;  // column c = table * m + bit
     const int tj = c / m, b = c % m;
-    dictm[e] = tj < n ? dict[((size_t)tj * dim + i) * m + b] : 0.f;
+    dictm[e] = (tj < n && i < dim) ? dict[((size_t)tj * dim + i) * m + b] : 0.f;
   }
 }
 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaChunk = 32;  // dims per step: 8 lanes x 16 B = one full 128-byte line per row
+constexpr int kMfmaChunk = kMfmaChunkC;  // dims per step: 8 lanes x 16 B = one full 128-byte line per row
 
+// Epilogue shared by the matrix-core projection kernels: the wave's 4 x CT accumulator tiles are
+// transposed through its LDS tile so that lane l holds the n*m projections of row row0 + l, then
+// sign codes, the g least-confident bits and the bucket histogram as in the VALU kernel.  Rows at
+// and past row_limit are not written.
 template <int CT, bool IS_QUERY, int GMAX>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 3 ? 3 : 2))) void project_mfma_kernel(
-    const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
-    const float *__restrict__ dictm,     // [dim][16*CT], column = table*m + bit, zero padded
-    uint32_t *__restrict__ codes, uint32_t *__restrict__ masks, uint8_t *__restrict__ u8img,
+__device__ __forceinline__ void project_mfma_epilogue(
+    const mfma_f4 (&acc)[4][CT], float *ws, int lane, long long row0, long long row_limit, long long nrows_total,
+    int m, int n, int g, uint32_t *__restrict__ codes, uint32_t *__restrict__ masks,
     uint32_t *__restrict__ counts, uint32_t *__restrict__ ranks, uint32_t hbmask, int nb) {
   constexpr int NC = 16 * CT;
-  constexpr int KS = kMfmaChunk / 4;   // MFMA k-steps per chunk
-  constexpr int NX = kMfmaChunk / 4;   // float4 loads per lane per chunk (64 rows x 32 dims / 64 lanes / 4)
-  constexpr int XS = kMfmaChunk + 1;   // floats per staged row (+1: spreads the rows over the banks)
-  constexpr int ES = NC + 1;           // floats per row of the transposed projections
-  constexpr int kWaveFloats = 64 * (ES > XS ? ES : XS);
-  __shared__ float lds[(kThreads / 64) * kWaveFloats];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float *ws = lds + wv * kWaveFloats;
-  const long long row0 = ((long long)blockIdx.x * (kThreads / 64) + wv) * 64;
-  if (row0 >= nrows) return;  // whole wave past the end (nothing below synchronises across waves)
+  constexpr int ES = NC + 1;
   const int r16 = lane & 15, q4 = lane >> 4;
-
-  mfma_f4 acc[4][CT];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma_f4{0.f, 0.f, 0.f, 0.f};
-
-  float4 px[NX];
-  // dims past the end of a row (dim % 32 == 16) are staged as zeros and multiply zero
-  // hyperplanes: fmaf(0, 0, acc) leaves every accumulator as it is
-  auto prefetch = [&](int c0) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const int e = lane + 64 * j;  // (row of the tile, 4-dim part of the step): 8 lanes per row
-      const long long grow = min(row0 + (e >> 3), (long long)nrows - 1);
-      const int d0 = c0 + 4 * (e & 7);
-      px[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (d0 < dim)  // read once: keep the rows out of the way of the hyperplanes in L1
-      {
-        const mfma_f4 t4 = __builtin_nontemporal_load(reinterpret_cast<const mfma_f4 *>(rows + (size_t)grow * dim + d0));
-        px[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
-      }
-    }
-  };
-  // hyperplane operand of one k-step, fetched one k-step ahead of its use (L1 / L2 resident)
-  float bn[CT];
-  auto fetch_b = [&](int k0) {
-    const int k = k0 + q4;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bn[ct] = k < dim ? dictm[(size_t)k * NC + 16 * ct + r16] : 0.f;
-  };
-  prefetch(0);
-  fetch_b(0);
-  for (int c0 = 0; c0 < dim; c0 += kMfmaChunk) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const int e = lane + 64 * j;
-      const int row = e >> 3, part = e & 7;
-      const float4 v = px[j];
-      float *dstp = ws + row * XS + 4 * part;
-      dstp[0] = v.x;
-      dstp[1] = v.y;
-      dstp[2] = v.z;
-      dstp[3] = v.w;
-      if (row0 + row < nrows && c0 + 4 * part < dim) {
-        const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
-        *reinterpret_cast<uint32_t *>(u8img + (size_t)(row0 + row) * dim + c0 + 4 * part) = pk;
-      }
-    }
-    if (c0 + kMfmaChunk < dim) prefetch(c0 + kMfmaChunk);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float bc[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) bc[ct] = bn[ct];
-      fetch_b(c0 + 4 * (ks + 1));  // the next k-step (of the next chunk after the last one; zeros past dim)
-      float a[4];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) a[rt] = ws[(16 * rt + r16) * XS + 4 * ks + q4];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bc[ct], acc[rt][ct], 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-
   // transpose: D tile element v of lane (r16, q4) is row 16*rt + 4*q4 + v, column 16*ct + r16
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
@@ -398,6 +322,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   const long long r = row0 + lane;
+  const long long nrows = row_limit;  // rows at and past it belong to nobody here
   const float *mine = ws + lane * ES;
   for (int j = 0; j < n; ++j) {
     uint32_t code = 0;
@@ -439,18 +364,129 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 
       }
     }
     if (r < nrows) {
-      codes[(size_t)j * nrows + r] = code;
+      codes[(size_t)j * nrows_total + r] = code;
       if (!IS_QUERY && counts)
-        ranks[(size_t)j * nrows + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
+        ranks[(size_t)j * nrows_total + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
     }
     if (IS_QUERY) {
       uint32_t mask = 0;
 #pragma unroll
       for (int q = 0; q < GMAX; ++q)
         if (q < g && bbit[q] >= 0) mask |= 1u << bbit[q];
-      if (r < nrows) masks[(size_t)j * nrows + r] = mask;
+      if (r < nrows) masks[(size_t)j * nrows_total + r] = mask;
     }
   }
+}
+
+template <int CT, bool IS_QUERY, int GMAX, bool FULL>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 3 ? 3 : 2))) void project_mfma_kernel(
+    const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
+    const float *__restrict__ dictm,     // [roundup(dim, 32)][16*CT], column = table*m + bit, zero padded
+    uint32_t *__restrict__ codes, uint32_t *__restrict__ masks, uint8_t *__restrict__ u8img,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ ranks, uint32_t hbmask, int nb) {
+  constexpr int NC = 16 * CT;
+  constexpr int KS = kMfmaChunk / 4;   // MFMA k-steps per chunk
+  constexpr int NX = kMfmaChunk / 4;   // float4 loads per lane per chunk (64 rows x 32 dims / 64 lanes / 4)
+  constexpr int XS = kMfmaChunk + 1;   // floats per staged row (+1: spreads the rows over the banks)
+  constexpr int ES = NC + 1;           // floats per row of the transposed projections
+  constexpr int kWaveFloats = 64 * (ES > XS ? ES : XS);
+  __shared__ float lds[(kThreads / 64) * kWaveFloats];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *ws = lds + wv * kWaveFloats;
+  const long long row0 = ((long long)blockIdx.x * (kThreads / 64) + wv) * 64;
+  if (row0 >= nrows) return;  // whole wave past the end (nothing below synchronises across waves)
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int quad = lane & 3;
+
+  mfma_f4 acc[4][CT];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+  float4 px[NX];
+  // FULL: dim is a whole number of 32-dim chunks, every load is unconditional.  Otherwise
+  // (dim % 32 == 16) the dims past the end of a row are staged as zeros and multiply the zero
+  // rows the repacked dictionary is padded with: fmaf(0, 0, acc) leaves every accumulator as it is
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = lane + 64 * j;  // (row of the tile, 4-dim part of the step): 8 lanes per row
+      const long long grow = min(row0 + (e >> 3), (long long)nrows - 1);
+      const int d0 = c0 + 4 * (e & 7);
+      if (FULL || d0 < dim) {  // read once: keep the rows out of the way of the hyperplanes in L1
+        const mfma_f4 t4 = __builtin_nontemporal_load(reinterpret_cast<const mfma_f4 *>(rows + (size_t)grow * dim + d0));
+        px[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+      } else {
+        px[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  // Hyperplane operands of a whole chunk (KS k-steps x CT column tiles, L1 / L2 resident), requested
+  // right after the previous chunk's MFMAs -- i.e. AFTER that chunk's row prefetch and BEFORE this
+  // chunk's stores and the next row prefetch.  Vector-memory operations of a wave complete in issue
+  // order (s_waitcnt vmcnt counts the youngest N): fetched inside the MFMA loop, behind the
+  // prefetch, every operand wait would also wait for the HBM stream.
+  float bq[KS][CT];
+  auto fetch_b_chunk = [&](int c0) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) bq[ks][ct] = dictm[(size_t)(c0 + 4 * ks + q4) * NC + 16 * ct + r16];
+  };
+  prefetch(0);
+  fetch_b_chunk(0);
+  for (int c0 = 0; c0 < dim; c0 += kMfmaChunk) {
+    // stage the chunk in LDS (A operand order) and assemble the uint8 image: the four lanes of a
+    // quad hold 16 consecutive bytes of a row; quad broadcasts give every lane all four dwords,
+    // lane t of the quad keeps those of load j = t (mod 4), so that two 16-byte-per-lane stores
+    // per chunk replace eight 4-byte ones
+    uint4 keep = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = lane + 64 * j;
+      const int row = e >> 3, part = e & 7;
+      const float4 v = px[j];
+      float *dstp = ws + row * XS + 4 * part;
+      dstp[0] = v.x;
+      dstp[1] = v.y;
+      dstp[2] = v.z;
+      dstp[3] = v.w;
+      const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
+      const uint32_t g0 = __builtin_amdgcn_mov_dpp(pk, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
+      const uint32_t g1 = __builtin_amdgcn_mov_dpp(pk, 0x55, 0xF, 0xF, true);  // [1,1,1,1]
+      const uint32_t g2 = __builtin_amdgcn_mov_dpp(pk, 0xAA, 0xF, 0xF, true);  // [2,2,2,2]
+      const uint32_t g3 = __builtin_amdgcn_mov_dpp(pk, 0xFF, 0xF, 0xF, true);  // [3,3,3,3]
+      if (quad == (j & 3)) keep = make_uint4(g0, g1, g2, g3);
+      if ((j & 3) == 3) {
+        const int krow = 8 * ((j & ~3) + quad) + (lane >> 3);  // row of the load this lane kept
+        const int kbyte = c0 + 16 * ((lane & 7) >> 2);         // first byte of the quad's 16
+        if (row0 + krow < nrows && (FULL || kbyte < dim))
+          *reinterpret_cast<uint4 *>(u8img + (size_t)(row0 + krow) * dim + kbyte) = keep;
+      }
+    }
+    if (c0 + kMfmaChunk < dim) prefetch(c0 + kMfmaChunk);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float a[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) a[rt] = ws[(16 * rt + r16) * XS + 4 * ks + q4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ks][ct], acc[rt][ct], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c0 + kMfmaChunk < dim) fetch_b_chunk(c0 + kMfmaChunk);
+  }
+
+  project_mfma_epilogue<CT, IS_QUERY, GMAX>(acc, ws, lane, row0, nrows, nrows, m, n, g, codes, masks, counts, ranks,
+                                            hbmask, nb);
 }
 
 // ---------------------------------------------------------------------------------
@@ -923,7 +959,7 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
     return o;
   };
   L.off_dictp = take((size_t)n * dim * L.mc * sizeof(float));
-  L.off_dictm = take((size_t)dim * 64 * sizeof(float));  // MFMA layout, at most 64 columns
+  L.off_dictm = take((size_t)(dim + 16) * 64 * sizeof(float));  // MFMA layout, at most 64 columns, rows padded to a multiple of 32
   L.off_ux = take((size_t)xrows * dim);
   L.off_uy = take((size_t)yrows * dim);
   L.off_xcodes = take((size_t)n * xrows * sizeof(uint32_t));
@@ -1002,15 +1038,23 @@ void launch_project_mfma(int g, const float *rows, int nrows, int dim, int m, in
   if (nrows <= 0) return;
   const int ct = (n * m + 15) / 16;
   const dim3 grid((nrows + kThreads - 1) / kThreads), block(kThreads);
-  constexpr int G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
+  constexpr int G0 = IS_QUERY ? 2 : 1, G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
+  const bool full = dim % kMfmaChunk == 0;
+#define SPV_LAUNCH_ONE(CTV, GV, FULLV)                                                               \
+  hipLaunchKernelGGL((project_mfma_kernel<CTV, IS_QUERY, GV, FULLV>), grid, block, 0, stream, rows,  \
+                     nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb)
 #define SPV_LAUNCH_MFMA(CTV)                                                                         \
   case CTV:                                                                                          \
-    if (g <= G1)                                                                                     \
-      hipLaunchKernelGGL((project_mfma_kernel<CTV, IS_QUERY, G1>), grid, block, 0, stream, rows,     \
-                         nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb);  \
-    else                                                                                             \
-      hipLaunchKernelGGL((project_mfma_kernel<CTV, IS_QUERY, G2>), grid, block, 0, stream, rows,     \
-                         nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb);  \
+    if (g <= G0) {                                                                                   \
+      if (full) SPV_LAUNCH_ONE(CTV, G0, true);                                                       \
+      else SPV_LAUNCH_ONE(CTV, G0, false);                                                           \
+    } else if (g <= G1) {                                                                            \
+      if (full) SPV_LAUNCH_ONE(CTV, G1, true);                                                       \
+      else SPV_LAUNCH_ONE(CTV, G1, false);                                                           \
+    } else {                                                                                         \
+      if (full) SPV_LAUNCH_ONE(CTV, G2, true);                                                       \
+      else SPV_LAUNCH_ONE(CTV, G2, false);                                                           \
+    }                                                                                                \
     break;
   switch (ct) {
     SPV_LAUNCH_MFMA(1)
@@ -1019,6 +1063,7 @@ void launch_project_mfma(int g, const float *rows, int nrows, int dim, int m, in
     default:
       SPV_LAUNCH_MFMA(4)
   }
+#undef SPV_LAUNCH_ONE
 #undef SPV_LAUNCH_MFMA
 }
 

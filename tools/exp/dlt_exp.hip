@@ -7,6 +7,7 @@
 namespace spv {
 int set_error(int s, const char *, ...) { return s; }
 void clear_error() {}
+int device_cu_count() { return 256; }
 ProfScope::ProfScope(const char *n, hipStream_t s) : name_(n), stream_(s) {}
 ProfScope::~ProfScope() {}
 namespace {
@@ -138,6 +139,102 @@ __global__ __launch_bounds__(kDltThreads) void v5_wave_lds(Cameras cam, long lon
     }
   }
 }
+
+// V6: v4 with the prefetch two points deep (12 more VGPRs, twice the bytes in flight per wave)
+__global__ __launch_bounds__(kDltThreads) void v6_wave2(Cameras cam, long long npt, const double *__restrict__ x,
+                                                         const double *__restrict__ xp, double *__restrict__ dst) {
+  const long long stride = (long long)gridDim.x * kDltThreads;
+  long long p = (long long)blockIdx.x * kDltThreads + threadIdx.x;
+  double a[2][3], b[2][3];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long q = p + k * stride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a[k][i] = 1.0; b[k][i] = 1.0; }
+    if (q < npt) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { a[k][i] = x[3 * q + i]; b[k][i] = xp[3 * q + i]; }
+    }
+  }
+  for (; p < npt; p += 2 * stride) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const long long cur = p + k * stride;
+      const double c0 = a[k][0], c1 = a[k][1], c2 = a[k][2], d0 = b[k][0], d1 = b[k][1], d2 = b[k][2];
+      const long long q = cur + 2 * stride;
+      if (q < npt) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a[k][i] = x[3 * q + i]; b[k][i] = xp[3 * q + i]; }
+      }
+      if (cur < npt) {
+        double X[4], u, v, up, vp;
+        dlt_solve<true>(cam, c0, c1, c2, d0, d1, d2, X, u, v, up, vp);
+        double4 *o = reinterpret_cast<double4 *>(dst) + cur;
+        *o = make_double4(X[0], X[1], X[2], X[3]);
+      }
+    }
+  }
+}
+
+// V7: independent waves, persistent; the 1536-byte span of each view travels HBM -> LDS directly
+// (global_load_lds_dwordx4, 16 bytes per lane, no staging registers), NS batches in flight per wave.
+template <int NS>
+__global__ __launch_bounds__(kDltThreads) void v7_ldsdma(Cameras cam, long long npt, const double *__restrict__ x,
+                                                          const double *__restrict__ xp, double *__restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 waves][NS][2 views][1536 B]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  char *wbase = smem + (size_t)wv * NS * 3072;
+  const long long nw = (npt + 63) / 64;
+  const long long wstride = (long long)gridDim.x * (kDltThreads / 64);
+  long long w = (long long)blockIdx.x * (kDltThreads / 64) + wv;
+  typedef const __attribute__((address_space(1))) void *gptr;
+  typedef __attribute__((address_space(3))) void *lptr;
+  auto issue = [&](long long ww, int slot) {
+    if (ww >= nw) return;  // wave-uniform
+    const long long base = ww * 64;
+    const long long nbytes = min(64LL, npt - base) * 24;  // valid bytes of the span
+    const char *gx = reinterpret_cast<const char *>(x) + base * 24;
+    const char *gp = reinterpret_cast<const char *>(xp) + base * 24;
+    char *l = wbase + slot * 3072;
+    if (lane * 16 < nbytes) {
+      __builtin_amdgcn_global_load_lds((gptr)(gx + lane * 16), (lptr)(l), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(gp + lane * 16), (lptr)(l + 1536), 16, 0, 0);
+    }
+    if (lane < 32 && 1024 + lane * 16 < nbytes) {
+      __builtin_amdgcn_global_load_lds((gptr)(gx + 1024 + lane * 16), (lptr)(l + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(gp + 1024 + lane * 16), (lptr)(l + 1536 + 1024), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(w + s * wstride, s);
+  int slot = 0;
+  for (; w < nw; w += wstride) {
+    issue(w + (NS - 1) * wstride, (slot + NS - 1) % NS);
+    // the oldest batch has landed when at most the (NS-1) younger batches' loads are outstanding;
+    // every batch issues up to 4 loads, so wait for all but 4*(NS-1) (conservative at the tail)
+    if (NS == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);        // vmcnt(4)
+    else if (NS == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);   // vmcnt(8)
+    else __builtin_amdgcn_s_waitcnt(0x0F70 | 12);               // vmcnt(12)
+    if (w + (NS - 1) * wstride >= nw) __builtin_amdgcn_s_waitcnt(0x0F70);  // tail: vmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    const double *lx = reinterpret_cast<const double *>(wbase + slot * 3072);
+    const double *lp = reinterpret_cast<const double *>(wbase + slot * 3072 + 1536);
+    const long long base = w * 64;
+    double c0 = 1, c1 = 1, c2 = 1, d0 = 1, d1 = 1, d2 = 1;
+    if (base + lane < npt) {
+      c0 = lx[3 * lane]; c1 = lx[3 * lane + 1]; c2 = lx[3 * lane + 2];
+      d0 = lp[3 * lane]; d1 = lp[3 * lane + 1]; d2 = lp[3 * lane + 2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (base + lane < npt) {
+      double X[4], u, v, up, vp;
+      dlt_solve<true>(cam, c0, c1, c2, d0, d1, d2, X, u, v, up, vp);
+      double4 *o = reinterpret_cast<double4 *>(dst) + (base + lane);
+      *o = make_double4(X[0], X[1], X[2], X[3]);
+    }
+    slot = (slot + 1) % NS;
+  }
+}
 }  // namespace
 }  // namespace spv
 using namespace spv;
@@ -183,6 +280,33 @@ int main(int argc, char **argv) {
     char nm[64]; snprintf(nm, sizeof nm, "v5 wave lds %d blk/CU", per);
     timeit(nm, [&] { hipLaunchKernelGGL(v5_wave_lds, dim3(256 * per), dim3(kDltThreads), 0, 0, cam, npt, dx, dxp, dd2); });
   }
+  auto compare = [&](const char *name) {
+    std::vector<double> a(4 * npt), b(4 * npt);
+    hipMemcpy(a.data(), dd, a.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(b.data(), dd2, b.size() * 8, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < a.size(); i++) bad += a[i] != b[i];
+    printf("%s vs v0 mismatches over all points: %zu\n", name, bad); fflush(stdout);
+    hipMemset(dd2, 0, 32 * npt);
+  };
+  for (int per : {8, 16, 32}) {
+    char nm[64]; snprintf(nm, sizeof nm, "v6 wave depth2 %d blk/CU", per);
+    timeit(nm, [&] { hipLaunchKernelGGL(v6_wave2, dim3(256 * per), dim3(kDltThreads), 0, 0, cam, npt, dx, dxp, dd2); });
+  }
+  compare("v6");
+  for (int per : {4, 8}) {
+    char nm[64]; snprintf(nm, sizeof nm, "v7 lds-dma NS=2 %d blk/CU", per);
+    timeit(nm, [&] { hipLaunchKernelGGL((v7_ldsdma<2>), dim3(256 * per), dim3(kDltThreads), 4 * 2 * 3072, 0, cam, npt, dx, dxp, dd2); });
+  }
+  compare("v7<2>");
+  for (int per : {4, 8}) {
+    char nm[64]; snprintf(nm, sizeof nm, "v7 lds-dma NS=3 %d blk/CU", per);
+    timeit(nm, [&] { hipLaunchKernelGGL((v7_ldsdma<3>), dim3(256 * per), dim3(kDltThreads), 4 * 3 * 3072, 0, cam, npt, dx, dxp, dd2); });
+  }
+  compare("v7<3>");
+  for (int per : {4}) {
+    char nm[64]; snprintf(nm, sizeof nm, "v7 lds-dma NS=4 %d blk/CU", per);
+    timeit(nm, [&] { hipLaunchKernelGGL((v7_ldsdma<4>), dim3(256 * per), dim3(kDltThreads), 4 * 4 * 3072, 0, cam, npt, dx, dxp, dd2); });
+  }
+  compare("v7<4>");
   std::vector<double> a(4 * 100000), b(4 * 100000);
   hipMemcpy(a.data(), dd, a.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(b.data(), dd2, b.size() * 8, hipMemcpyDeviceToHost);
   size_t bad = 0; for (size_t i = 0; i < a.size(); i++) bad += a[i] != b[i];
