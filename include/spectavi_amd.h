@@ -198,6 +198,39 @@ int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int 
                              const double *x, const double *xp, double max_error,
                              int32_t *counts, uint8_t *mask);
 
+/* What the reference's RANSAC does with each candidate fundamental matrix,
+ * RansacFitter::process_fundamental_matrix (reference src/RansacFitter.h:42-95), batched over nF
+ * candidates Fs double[nF,3,3] and all npt correspondences x0, x1 double[npt,3]:
+ *   - JacobiSVD of F; gate_ratio = |s0 - s1| / (|s0 + s1| / 2); candidates with
+ *     gate_ratio > singular_value_ratio_allowed are rejected (:49-53);
+ *   - E = U diag(1,1,0) V^T (:54-56) and its four candidate second cameras, Essential2Cameras
+ *     (src/Camera.h:31-46), against the first camera [I | 0];
+ *   - every camera scored over all correspondences (spv_dlt_score_hypotheses' rule, :59-73);
+ *   - in camera order, a camera becomes the best when its inlier fraction reaches
+ *     required_percent_inliers (or find_best_even_in_failure) and exceeds the best so far (:74-84).
+ * Outputs per candidate: success int32[nF] (0/1), inlier_count int32[nF], best_camera int32[nF]
+ * (0..3 in the order (Ra,t) (Ra,-t) (Rb,t) (Rb,-t), -1 if none); optional (NULL to skip): best_P
+ * double[nF,3,4] (zeros if none), gate_ratio double[nF], E double[nF,3,3] (NaN if gated), counts4
+ * int32[nF,4] (-1 if gated), inlier_mask uint8[nF,npt] = inliers of the best camera (the
+ * reference's inlier_idx, :86-94, as a mask).  The two SVDs run the same two-sided Jacobi iteration
+ * as Eigen's JacobiSVD (which of the four cameras comes first depends on its column signs). */
+int spv_ransac_process_candidates(const double *Fs, int nF, const double *x0, const double *x1, int npt,
+                                  double singular_value_ratio_allowed, double required_percent_inliers,
+                                  double reprojection_error_allowed, int find_best_even_in_failure,
+                                  int32_t *success, int32_t *inlier_count, int32_t *best_camera,
+                                  double *best_P, double *gate_ratio, double *E, int32_t *counts4,
+                                  uint8_t *inlier_mask);
+/* Device form: everything resident in HBM, nF <= 16383 per call, d_ws >=
+ * spv_ransac_workspace_bytes(nF, npt, d_inlier_mask != NULL). */
+size_t spv_ransac_workspace_bytes(int nF, long long npt, int want_mask);
+int spv_ransac_process_candidates_device(const double *d_Fs, int nF, long long npt, const double *d_x0,
+                                         const double *d_x1, double singular_value_ratio_allowed,
+                                         double required_percent_inliers, double reprojection_error_allowed,
+                                         int find_best_even_in_failure, int32_t *d_success,
+                                         int32_t *d_inlier_count, int32_t *d_best_camera, double *d_best_P,
+                                         double *d_gate_ratio, double *d_E, int32_t *d_counts4,
+                                         uint8_t *d_inlier_mask, void *d_ws, size_t ws_bytes, void *stream);
+
 int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                         const double *xp, double *dst);
 int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,

@@ -587,6 +587,58 @@ int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const
   return SPV_OK;
 }
 
+int host_ransac_process(const double *Fs, int nF, const double *x0, const double *x1, int npt,
+                        double ratio_allowed, double required_percent, double max_error, int find_best,
+                        int32_t *success, int32_t *inlier_count, int32_t *best_cam, double *best_P, double *ratio,
+                        double *E, int32_t *counts4, uint8_t *mask) {
+  if (nF < 0 || npt < 0) return set_error(SPV_ERR_INVALID, "negative count");
+  if (nF == 0) return SPV_OK;
+  if (npt == 0) return set_error(SPV_ERR_INVALID, "no correspondences");
+  if (!Fs || !x0 || !x1 || !success || !inlier_count || !best_cam) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  // candidates per launch: the scoring grid takes 65535 hypotheses (4 per candidate) and the
+  // per-camera masks are kept under 1 GiB
+  int chunk = 16383;
+  if (mask) chunk = (int)std::max<long long>(1, std::min<long long>(chunk, ((long long)1 << 28) / npt));
+  chunk = std::min(chunk, nF);
+  const size_t ib = (size_t)npt * 3 * sizeof(double);
+  const size_t wsb = ransac_workspace_bytes(chunk, npt, mask != nullptr);
+  DevBuf dx, dxp, dF, ds, dc, db, dP, dr, dE, d4, dm, ws;
+  SPV_TRY(dx.alloc(ib));
+  SPV_TRY(dxp.alloc(ib));
+  SPV_TRY(dF.alloc((size_t)chunk * 9 * sizeof(double)));
+  SPV_TRY(ds.alloc((size_t)chunk * sizeof(int32_t)));
+  SPV_TRY(dc.alloc((size_t)chunk * sizeof(int32_t)));
+  SPV_TRY(db.alloc((size_t)chunk * sizeof(int32_t)));
+  SPV_TRY(dP.alloc((size_t)chunk * 12 * sizeof(double)));
+  SPV_TRY(dr.alloc((size_t)chunk * sizeof(double)));
+  SPV_TRY(dE.alloc((size_t)chunk * 9 * sizeof(double)));
+  SPV_TRY(d4.alloc((size_t)chunk * 4 * sizeof(int32_t)));
+  if (mask) SPV_TRY(dm.alloc((size_t)chunk * npt));
+  SPV_TRY(ws.alloc(wsb));
+  hipStream_t st = hipStreamPerThread;
+  SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x0, ib, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, x1, ib, hipMemcpyHostToDevice, st));
+  for (int f0 = 0; f0 < nF; f0 += chunk) {
+    const int nf = std::min(chunk, nF - f0);
+    SPV_HIP_CHECK(hipMemcpyAsync(dF.p, Fs + (size_t)f0 * 9, (size_t)nf * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+    SPV_TRY(ransac_process_run(dF.as<double>(), nf, npt, dx.as<double>(), dxp.as<double>(), ratio_allowed,
+                               required_percent, max_error, find_best, ds.as<int>(), dc.as<int>(), db.as<int>(),
+                               dP.as<double>(), dr.as<double>(), dE.as<double>(), d4.as<int>(),
+                               mask ? dm.as<unsigned char>() : nullptr, ws.p, wsb, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(success + f0, ds.p, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(inlier_count + f0, dc.p, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(best_cam + f0, db.p, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (best_P) SPV_HIP_CHECK(hipMemcpyAsync(best_P + (size_t)f0 * 12, dP.p, (size_t)nf * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (ratio) SPV_HIP_CHECK(hipMemcpyAsync(ratio + f0, dr.p, (size_t)nf * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (E) SPV_HIP_CHECK(hipMemcpyAsync(E + (size_t)f0 * 9, dE.p, (size_t)nf * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (counts4) SPV_HIP_CHECK(hipMemcpyAsync(counts4 + (size_t)f0 * 4, d4.p, (size_t)nf * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (mask) SPV_HIP_CHECK(hipMemcpyAsync(mask + (size_t)f0 * npt, dm.p, (size_t)nf * npt, hipMemcpyDeviceToHost, st));
+    SPV_HIP_CHECK(hipStreamSynchronize(st));  // the staging buffers are reused by the next chunk
+  }
+  return SPV_OK;
+}
+
 int host_ratio(const uint64_t *idx, const void *dist, int dist_is_float, int yrows, double min_ratio,
                int32_t *matches, int32_t *count) {
   if (yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
@@ -1137,6 +1189,36 @@ int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int 
                              int32_t *counts, uint8_t *mask) {
   clear_error();
   return host_guard([&] { return host_dlt_score(P0, P1s, nhyp, npt, x, xp, max_error, counts, mask); });
+}
+int spv_ransac_process_candidates(const double *Fs, int nF, const double *x0, const double *x1, int npt,
+                                  double singular_value_ratio_allowed, double required_percent_inliers,
+                                  double reprojection_error_allowed, int find_best_even_in_failure,
+                                  int32_t *success, int32_t *inlier_count, int32_t *best_camera, double *best_P,
+                                  double *gate_ratio, double *E, int32_t *counts4, uint8_t *inlier_mask) {
+  clear_error();
+  return host_guard([&] {
+    return host_ransac_process(Fs, nF, x0, x1, npt, singular_value_ratio_allowed, required_percent_inliers,
+                               reprojection_error_allowed, find_best_even_in_failure, success, inlier_count,
+                               best_camera, best_P, gate_ratio, E, counts4, inlier_mask);
+  });
+}
+size_t spv_ransac_workspace_bytes(int nF, long long npt, int want_mask) {
+  return (nF < 0 || npt < 0) ? 0 : ransac_workspace_bytes(nF, npt, want_mask != 0);
+}
+int spv_ransac_process_candidates_device(const double *d_Fs, int nF, long long npt, const double *d_x0,
+                                         const double *d_x1, double singular_value_ratio_allowed,
+                                         double required_percent_inliers, double reprojection_error_allowed,
+                                         int find_best_even_in_failure, int32_t *d_success, int32_t *d_inlier_count,
+                                         int32_t *d_best_camera, double *d_best_P, double *d_gate_ratio, double *d_E,
+                                         int32_t *d_counts4, uint8_t *d_inlier_mask, void *d_ws, size_t ws_bytes,
+                                         void *stream) {
+  clear_error();
+  return guard([&] {
+    return ransac_process_run(d_Fs, nF, npt, d_x0, d_x1, singular_value_ratio_allowed, required_percent_inliers,
+                              reprojection_error_allowed, find_best_even_in_failure, d_success, d_inlier_count,
+                              d_best_camera, d_best_P, d_gate_ratio, d_E, d_counts4, d_inlier_mask, d_ws, ws_bytes,
+                              static_cast<hipStream_t>(stream));
+  });
 }
 int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int nhyp,
                                     long long npt, const double *d_x, const double *d_xp,

@@ -109,4 +109,13 @@ int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,
                   hipStream_t stream);
 
+
+// ---- RANSAC candidate processing (dlt.hip): gate, E, four cameras, scoring, best camera ----
+size_t ransac_workspace_bytes(int nF, long long npt, bool want_mask);
+int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *d_x0, const double *d_x1,
+                       double ratio_allowed, double required_percent, double max_error, int find_best,
+                       int *d_success, int *d_inlier_count, int *d_best_cam, double *d_best_P, double *d_ratio,
+                       double *d_E, int *d_counts4, unsigned char *d_mask, void *d_ws, size_t ws_bytes,
+                       hipStream_t stream);
+
 }  // namespace spv

@@ -321,6 +321,10 @@ __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
   }
   const long long base = (long long)blockIdx.x * kDltThreads;
   const long long nblk = min((long long)kDltThreads, npt - base);
+  if (cam.p1[0] != cam.p1[0]) {  // NaN camera = a gated RANSAC candidate (workgroup-uniform): nothing is an inlier
+    if (mask && threadIdx.x < nblk) mask[(size_t)h * npt + base + threadIdx.x] = 0;
+    return;
+  }
   for (int e = threadIdx.x; e < nblk * 3; e += kDltThreads) {
     sx[e] = x[base * 3 + e];
     sxp[e] = xp[base * 3 + e];
@@ -359,7 +363,329 @@ __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[h], __popcll(bal));
 }
 
+
+// ---------------------------------------------------------------------------------
+// RANSAC candidate processing (the rest of it): what the reference's
+// process_fundamental_matrix does with ONE candidate F (src/RansacFitter.h:42-95), batched over
+// many candidates:  SVD of F, singular-value-ratio gate (:49-53), E = U diag(1,1,0) V^T (:54-56),
+// Essential2Cameras (src/Camera.h:31-46: a second SVD, t = U.col(2), Ra = U D V^T, Rb = U D^T V^T,
+// cameras (Ra,t) (Ra,-t) (Rb,t) (Rb,-t)), every camera scored over all correspondences by
+// dlt_score_kernel above, the best camera kept by the rule of :74-94.
+//
+// Which of the four cameras is "Ra, +t" depends on the signs Eigen's JacobiSVD happens to give the
+// columns of U and V (sigma3 = 0 leaves u3 and v3 unpaired: det(U V^T) may be -1 and the reference
+// does not correct it).  To stay a drop-in, the SVD here is the same published two-sided Jacobi
+// iteration (Eigen 3.3 / 3.4 JacobiSVD.h, real_2x2_jacobi_svd, makeJacobi: scale by the largest
+// entry, sweeps over (p,q) = (1,0) (2,0) (2,1) until every off-diagonal pair is below
+// 2 eps * max|diagonal|, signs into U, selection sort), with products and sums rounded separately as
+// the reference's build (no -march, no FMA) rounds them.
+// ---------------------------------------------------------------------------------
+struct JRot {  // J = [c s; -s c]
+  double c, s;
+};
+
+template <int P, int Q>
+__device__ __forceinline__ void rot_rows(double (&M)[3][3], JRot j) {  // B = J B on rows P, Q
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double xi = M[P][i], yi = M[Q][i];
+    M[P][i] = j.c * xi + j.s * yi;
+    M[Q][i] = -j.s * xi + j.c * yi;
+  }
+}
+
+template <int P, int Q>
+__device__ __forceinline__ void rot_cols(double (&M)[3][3], JRot j) {  // B = B J on columns P, Q
+  const double c = j.c, s = -j.s;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double xi = M[i][P], yi = M[i][Q];
+    M[i][P] = c * xi + s * yi;
+    M[i][Q] = -s * xi + c * yi;
+  }
+}
+
+__device__ __forceinline__ JRot make_jacobi(double x, double y, double z) {
+  const double kMin = 2.2250738585072014e-308;
+  const double deno = 2.0 * fabs(y);
+  if (deno < kMin) return JRot{1.0, 0.0};
+  const double tau = (x - z) / deno;
+  const double w = sqrt(tau * tau + 1.0);
+  const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+  const double sign_t = t > 0.0 ? 1.0 : -1.0;
+  const double n = 1.0 / sqrt(t * t + 1.0);
+  return JRot{n, -sign_t * (y / fabs(y)) * fabs(t) * n};
+}
+
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_pair(double (&W)[3][3], double (&U)[3][3], double (&V)[3][3],
+                                            double &max_diag, bool &finished) {
+  const double kMin = 2.2250738585072014e-308, kPrecision = 2.0 * 2.220446049250313e-16;
+  const double threshold = fmax(kMin, kPrecision * max_diag);
+  if (fabs(W[P][Q]) > threshold || fabs(W[Q][P]) > threshold) {
+    finished = false;
+    // 2x2 real Jacobi SVD of [[W(p,p) W(p,q)] [W(q,p) W(q,q)]]
+    double m00 = W[P][P], m01 = W[P][Q], m10 = W[Q][P], m11 = W[Q][Q];
+    JRot rot1;
+    const double t = m00 + m11;
+    const double d = m10 - m01;
+    if (fabs(d) < kMin) {
+      rot1 = JRot{1.0, 0.0};
+    } else {
+      const double u = t / d;
+      const double tmp = sqrt(1.0 + u * u);
+      rot1 = JRot{u / tmp, 1.0 / tmp};
+    }
+    {  // m = rot1 applied to its rows
+      const double a0 = rot1.c * m00 + rot1.s * m10, a1 = rot1.c * m01 + rot1.s * m11;
+      const double b1 = -rot1.s * m01 + rot1.c * m11;
+      m00 = a0;
+      m01 = a1;
+      m11 = b1;
+    }
+    const JRot j_right = make_jacobi(m00, m01, m11);
+    const JRot jrt{j_right.c, -j_right.s};
+    const JRot j_left{rot1.c * jrt.c - rot1.s * jrt.s, rot1.c * jrt.s + rot1.s * jrt.c};
+    rot_rows<P, Q>(W, j_left);
+    rot_cols<P, Q>(U, JRot{j_left.c, -j_left.s});
+    rot_cols<P, Q>(W, j_right);
+    rot_cols<P, Q>(V, j_right);
+    max_diag = fmax(max_diag, fmax(fabs(W[P][P]), fabs(W[Q][Q])));
+  }
+}
+
+template <int I, int J>
+__device__ __forceinline__ void swap_cols_if(bool c, double (&S)[3], double (&U)[3][3], double (&V)[3][3]) {
+  const double s = S[I];
+  S[I] = c ? S[J] : S[I];
+  S[J] = c ? s : S[J];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double u = U[r][I], v = V[r][I];
+    U[r][I] = c ? U[r][J] : u;
+    U[r][J] = c ? u : U[r][J];
+    V[r][I] = c ? V[r][J] : v;
+    V[r][J] = c ? v : V[r][J];
+  }
+}
+
+// A = U diag(S) V^T, S descending.
+__device__ __forceinline__ void jacobi_svd3(const double (&A)[3][3], double (&U)[3][3], double (&S)[3],
+                                            double (&V)[3][3]) {
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) scale = fmax(scale, fabs(A[i][j]));
+  if (scale == 0.0) scale = 1.0;
+  double W[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      W[i][j] = A[i][j] / scale;
+      U[i][j] = V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  double max_diag = fmax(fabs(W[0][0]), fmax(fabs(W[1][1]), fabs(W[2][2])));
+  bool finished = false;
+  // a 3x3 converges in a handful of sweeps; the cap only bounds the loop for lanes fed nan / inf
+  // (their comparisons are false, as in the reference, so they normally leave after one sweep)
+  for (int sweep = 0; sweep < 60 && !finished; ++sweep) {
+    finished = true;
+    jacobi_pair<1, 0>(W, U, V, max_diag, finished);
+    jacobi_pair<2, 0>(W, U, V, max_diag, finished);
+    jacobi_pair<2, 1>(W, U, V, max_diag, finished);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a = W[i][i];
+    S[i] = fabs(a) * scale;
+    if (a < 0.0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) U[r][i] = -U[r][i];
+    }
+  }
+  // selection sort, first maximum wins
+  {
+    int pos = 0;
+    if (S[1] > S[0]) pos = 1;
+    if (S[2] > (pos == 1 ? S[1] : S[0])) pos = 2;
+    swap_cols_if<0, 1>(pos == 1, S, U, V);
+    swap_cols_if<0, 2>(pos == 2, S, U, V);
+    swap_cols_if<1, 2>(S[2] > S[1], S, U, V);
+  }
+}
+
+__device__ __forceinline__ void mat3_mul(const double (&A)[3][3], const double (&B)[3][3], double (&C)[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a += A[i][k] * B[k][j];
+      C[i][j] = a;
+    }
+}
+
+// One lane per candidate F: gate, E, the four cameras.  cams double[nF,4,12]; gated candidates get
+// NaN cameras (the scoring kernel skips them) and gated[f] = 1.
+__global__ __launch_bounds__(kDltThreads) void essential_cameras_kernel(
+    const double *__restrict__ Fs, int nF, double ratio_allowed, double *__restrict__ cams,
+    double *__restrict__ ratio_out, double *__restrict__ E_out, int *__restrict__ gated) {
+  const int f = blockIdx.x * kDltThreads + threadIdx.x;
+  if (f >= nF) return;
+  double F[3][3], U[3][3], S[3], V[3][3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = Fs[(size_t)f * 9 + i];
+  jacobi_svd3(F, U, S, V);
+  const double ratio = fabs(S[0] - S[1]) / (fabs(S[0] + S[1]) / 2.);
+  if (ratio_out) ratio_out[f] = ratio;
+  const double nan = __builtin_nan("");
+  double *out = cams + (size_t)f * 48;
+  if (ratio > ratio_allowed) {  // src/RansacFitter.h:51-53 (a NaN ratio is not gated there either)
+    gated[f] = 1;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) out[i] = nan;
+    if (E_out)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) E_out[(size_t)f * 9 + i] = nan;
+    return;
+  }
+  gated[f] = 0;
+  double Ud[3][3], Vt[3][3], E[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Ud[i][j] = U[i][j] * (j < 2 ? 1.0 : 0.0);
+      Vt[i][j] = V[j][i];
+    }
+  mat3_mul(Ud, Vt, E);
+  if (E_out)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E_out[(size_t)f * 9 + i] = E[i / 3][i % 3];
+  // Essential2Cameras
+  jacobi_svd3(E, U, S, V);
+  const double D[3][3] = {{0, 1, 0}, {-1, 0, 0}, {0, 0, 1}};
+  const double Dt[3][3] = {{0, -1, 0}, {1, 0, 0}, {0, 0, 1}};
+  double UD[3][3], Ra[3][3], Rb[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Vt[i][j] = V[j][i];
+  mat3_mul(U, D, UD);
+  mat3_mul(UD, Vt, Ra);
+  mat3_mul(U, Dt, UD);
+  mat3_mul(UD, Vt, Rb);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double sg = (k & 1) ? -1.0 : 1.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[12 * k + 4 * r + c] = k < 2 ? Ra[r][c] : Rb[r][c];
+      out[12 * k + 4 * r + 3] = sg * U[r][2];
+    }
+  }
+}
+
+// The choice among the four cameras, src/RansacFitter.h:74-84: in camera order, a camera becomes the
+// best when it reaches required_percent (or find_best_even_in_failure) AND beats the best so far.
+__global__ __launch_bounds__(kDltThreads) void select_camera_kernel(
+    const int *__restrict__ counts, const int *__restrict__ gated, const double *__restrict__ cams, int nF,
+    long long npt, double required_percent, int find_best, int *__restrict__ success,
+    int *__restrict__ inlier_count, int *__restrict__ best_cam, double *__restrict__ best_P,
+    int *__restrict__ counts4) {
+  const int f = blockIdx.x * kDltThreads + threadIdx.x;
+  if (f >= nF) return;
+  int ok = 0, best = -1, nbest = 0;
+  if (!gated[f]) {
+    double best_percent = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ninlier = counts[4 * f + k];
+      const double percent = ninlier / (double)npt;
+      if ((percent >= required_percent || find_best) && percent > best_percent) {
+        best_percent = percent;
+        nbest = ninlier;
+        best = k;
+        ok = 1;
+      }
+    }
+  }
+  success[f] = ok;
+  inlier_count[f] = nbest;
+  best_cam[f] = best;
+  if (counts4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) counts4[4 * f + k] = gated[f] ? -1 : counts[4 * f + k];
+  if (best_P)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) best_P[(size_t)f * 12 + i] = ok ? cams[(size_t)f * 48 + 12 * best + i] : 0.0;
+}
+
+// mask[f, p] = inlier flag of candidate f's best camera (all zero when it has none).
+__global__ __launch_bounds__(kDltThreads) void best_mask_kernel(const unsigned char *__restrict__ mask4,
+                                                                const int *__restrict__ best_cam, long long npt,
+                                                                unsigned char *__restrict__ mask) {
+  const int f = blockIdx.y;
+  const int b = best_cam[f];
+  for (long long p = (long long)blockIdx.x * kDltThreads + threadIdx.x; p < npt; p += (long long)gridDim.x * kDltThreads)
+    mask[(size_t)f * npt + p] = b >= 0 ? mask4[((size_t)4 * f + b) * npt + p] : 0;
+}
+
 }  // namespace
+
+size_t ransac_workspace_bytes(int nF, long long npt, bool want_mask) {
+  size_t b = round_up((size_t)nF * 48 * sizeof(double), 256);      // cameras
+  b += round_up((size_t)nF * 4 * sizeof(int), 256);                 // inlier counts
+  b += round_up((size_t)nF * sizeof(int), 256);                     // gate flags
+  if (want_mask) b += round_up((size_t)nF * 4 * (size_t)npt, 256);  // per-camera inlier masks
+  return b;
+}
+
+int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *d_x0, const double *d_x1,
+                       double ratio_allowed, double required_percent, double max_error, int find_best,
+                       int *d_success, int *d_inlier_count, int *d_best_cam, double *d_best_P, double *d_ratio,
+                       double *d_E, int *d_counts4, unsigned char *d_mask, void *d_ws, size_t ws_bytes,
+                       hipStream_t stream) {
+  if (nF < 0 || npt < 0) return set_error(SPV_ERR_INVALID, "negative count");
+  if (nF == 0) return SPV_OK;
+  if (!d_Fs || !d_success || !d_inlier_count || !d_best_cam || (npt > 0 && (!d_x0 || !d_x1)))
+    return set_error(SPV_ERR_INVALID, "null device pointer");
+  if (nF > 16383) return set_error(SPV_ERR_INVALID, "more than 16383 candidates per call");
+  if (npt == 0) return set_error(SPV_ERR_INVALID, "no correspondences");
+  const size_t need = ransac_workspace_bytes(nF, npt, d_mask != nullptr);
+  if (!d_ws || ws_bytes < need) return set_error(SPV_ERR_INVALID, "workspace too small: %zu < %zu", ws_bytes, need);
+  unsigned char *ws = static_cast<unsigned char *>(d_ws);
+  double *cams = reinterpret_cast<double *>(ws);
+  ws += round_up((size_t)nF * 48 * sizeof(double), 256);
+  int *counts = reinterpret_cast<int *>(ws);
+  ws += round_up((size_t)nF * 4 * sizeof(int), 256);
+  int *gated = reinterpret_cast<int *>(ws);
+  ws += round_up((size_t)nF * sizeof(int), 256);
+  unsigned char *mask4 = d_mask ? ws : nullptr;
+  const int fblocks = (nF + kDltThreads - 1) / kDltThreads;
+  {
+    ProfScope prof("ransac_cameras", stream);
+    hipLaunchKernelGGL(essential_cameras_kernel, dim3(fblocks), dim3(kDltThreads), 0, stream, d_Fs, nF,
+                       ratio_allowed, cams, d_ratio, d_E, gated);
+    SPV_HIP_CHECK(hipGetLastError());
+  }
+  const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // Camera(): Identity(3,4), src/Camera.h:27
+  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, stream));
+  hipLaunchKernelGGL(select_camera_kernel, dim3(fblocks), dim3(kDltThreads), 0, stream, counts, gated, cams, nF, npt,
+                     required_percent, find_best, d_success, d_inlier_count, d_best_cam, d_best_P, d_counts4);
+  SPV_HIP_CHECK(hipGetLastError());
+  if (d_mask) {
+    const unsigned mb = (unsigned)std::min<long long>((npt + kDltThreads - 1) / kDltThreads, 1024);
+    hipLaunchKernelGGL(best_mask_kernel, dim3(mb, (unsigned)nF), dim3(kDltThreads), 0, stream, mask4, d_best_cam, npt,
+                       d_mask);
+    SPV_HIP_CHECK(hipGetLastError());
+  }
+  return SPV_OK;
+}
 
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,

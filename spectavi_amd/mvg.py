@@ -109,3 +109,65 @@ def dlt_score_hypotheses(P0, P1s, x, xp, max_error, return_mask=False):
     check(_spv_dlt_score_hypotheses(P0, P1s.reshape(-1), nhyp, npt, x, xp, float(max_error), counts,
                                     mask.ctypes.data if return_mask else None))
     return (counts, mask.astype(bool)) if return_mask else counts
+
+
+# ==================================================================================
+# RANSAC candidate processing (reference src/RansacFitter.h:42-95 + src/Camera.h:31-46)
+# ==================================================================================
+_spv_ransac_process = clib.spv_ransac_process_candidates
+_spv_ransac_process.restype = ct.c_int
+_f64 = ndpointer(ct.c_double, flags="C_CONTIGUOUS")
+_i32 = ndpointer(ct.c_int32, flags="C_CONTIGUOUS")
+_spv_ransac_process.argtypes = [_f64, ct.c_int, _f64, _f64, ct.c_int, ct.c_double, ct.c_double, ct.c_double, ct.c_int,
+                                _i32, _i32, _i32, _f64, _f64, _f64, _i32, ct.c_void_p]
+
+
+def process_fundamental_matrices(Fs, x0, x1, options={'required_percent_inliers': .9,
+                                                     'reprojection_error_allowed': .5,
+                                                     'find_best_even_in_failure': True,
+                                                     'singular_value_ratio_allowed': 3e-2}, return_mask=False):
+    """
+    What the reference's `ransac_fitter` does with every candidate fundamental matrix of a trial
+    (`RansacFitter::process_fundamental_matrix`, reference src/RansacFitter.h:42-95), for a batch of
+    candidates at once: singular-value-ratio gate, E = U diag(1,1,0) V^T, the four candidate
+    second cameras of E (`Essential2Cameras`, src/Camera.h:31-46), every camera scored over all
+    correspondences against [I | 0], the best camera kept.  The option names and defaults are the
+    reference front-end's (spectavi/mvg.py:138-143).
+
+    Fs float64 [nF,3,3] (or [3,3]); x0, x1 float64 [npt,3] homogeneous.
+    Returns a dict of arrays over the candidates: success bool [nF], inlier_count int32 [nF],
+    inlier_percent float64 [nF], camera float64 [nF,3,4] (zeros where no camera qualified),
+    best_camera int32 [nF] (0..3, -1 = none), essential float64 [nF,3,3] (NaN where gated),
+    singular_value_ratio float64 [nF], counts4 int32 [nF,4] (-1 where gated) and, with
+    `return_mask`, inlier_mask bool [nF,npt] (np.flatnonzero of a row = the reference's inlier_idx).
+    """
+    Fs = np.ascontiguousarray(Fs, dtype=np.float64)
+    if Fs.ndim == 2:
+        Fs = Fs[None]
+    if Fs.ndim != 3 or Fs.shape[1:] != (3, 3):
+        raise TypeError('Fs must be [nF,3,3] fundamental matrices.')
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    if not (x0.ndim == 2 and x0.shape == x1.shape and x0.shape[1] == 3):
+        raise TypeError('Coords must be homogenous [npt,3] pairs.')
+    nF, npt = Fs.shape[0], x0.shape[0]
+    if npt < 1:
+        raise ValueError('Supplied no point matches.')
+    success = np.zeros(nF, np.int32)
+    count = np.zeros(nF, np.int32)
+    best = np.full(nF, -1, np.int32)
+    best_P = np.zeros((nF, 3, 4))
+    ratio = np.zeros(nF)
+    E = np.zeros((nF, 3, 3))
+    counts4 = np.zeros((nF, 4), np.int32)
+    mask = np.zeros((nF, npt), np.uint8) if return_mask else None
+    check(_spv_ransac_process(Fs.reshape(-1), nF, x0, x1, npt, float(options['singular_value_ratio_allowed']),
+                              float(options['required_percent_inliers']), float(options['reprojection_error_allowed']),
+                              int(bool(options['find_best_even_in_failure'])), success, count, best,
+                              best_P.reshape(-1), ratio, E.reshape(-1), counts4.reshape(-1),
+                              mask.ctypes.data if return_mask else None))
+    ret = {'success': success.astype(bool), 'inlier_count': count, 'inlier_percent': count / float(npt),
+           'camera': best_P, 'best_camera': best, 'essential': E, 'singular_value_ratio': ratio, 'counts4': counts4}
+    if return_mask:
+        ret['inlier_mask'] = mask.astype(bool)
+    return ret
