@@ -240,3 +240,50 @@ def test_dlt_fuzz_slice_on_the_mirror(oracle):
     except SystemExit as e:
         pytest.fail(str(e))
     assert n >= 20 and m >= 10
+
+
+def _small_rotation(rng, max_angle=0.3):
+    """Rotation by at most max_angle about a random axis (Rodrigues): keeps a scene in front of both cameras."""
+    a = rng.standard_normal(3)
+    a /= np.linalg.norm(a)
+    th = rng.uniform(-max_angle, max_angle)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def test_essential_to_cameras_and_candidate_processing_oracle(oracle):
+    """The oracle for SURVEY 8(f) row 1 (oracle_jacobisvd.cpp: src/Camera.h:31-46,
+    src/RansacFitter.h:42-95) pinned by LAPACK and by the geometry it must satisfy: the four
+    cameras of an essential matrix are (R, +-t) pairs with R orthogonal, t its unit left null vector
+    and [t]x R = +-E; on noise-free correspondences of a known motion the true camera (as a
+    projective camera: +-[R | t]) wins with every point an inlier; matrices whose two largest
+    singular values differ by more than the gate are rejected with the LAPACK ratio."""
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        R = _small_rotation(rng)
+        t = rng.standard_normal(3)
+        t /= np.linalg.norm(t)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        cams = oracle.essential_to_cameras(E)
+        for k in range(4):
+            Rk, tk = cams[k][:, :3], cams[k][:, 3]
+            assert np.allclose(Rk.T @ Rk, np.eye(3), atol=1e-12) and abs(abs(tk @ t) - 1) < 1e-12
+            tkx = np.array([[0, -tk[2], tk[1]], [tk[2], 0, -tk[0]], [-tk[1], tk[0], 0]])
+            assert min(np.abs(tkx @ Rk - E).max(), np.abs(tkx @ Rk + E).max()) < 1e-12
+        assert np.allclose(cams[0][:, :3], cams[1][:, :3]) and np.allclose(cams[0][:, 3], -cams[1][:, 3])
+        assert np.allclose(cams[2][:, :3], cams[3][:, :3]) and np.allclose(cams[2][:, 3], -cams[3][:, 3])
+        npt = 120
+        Xw = np.hstack([rng.standard_normal((npt, 2)), rng.uniform(4, 8, (npt, 1)), np.ones((npt, 1))])
+        P1 = np.hstack([R, t[:, None]])
+        x0, x1 = Xw[:, :3].copy(), Xw @ P1.T
+        r = oracle.process_fundamental_matrix(E * rng.uniform(0.2, 5) * rng.choice([-1, 1]), x0, x1, 3e-2, .9, 1e-3, False)
+        assert r["success"] and r["inlier_count"] == npt and r["gate_ratio"] < 1e-12
+        assert min(np.abs(r["best_P"] - P1).max(), np.abs(r["best_P"] + P1).max()) < 1e-9
+        assert np.array_equal(r["inlier_idx"], np.arange(npt)) and sorted(r["counts4"])[:3] == [0, 0, 0]
+        assert np.allclose(np.linalg.svd(r["E"], compute_uv=False), [1, 1, 0], atol=1e-12)
+        F = rng.standard_normal((3, 3))
+        s = np.linalg.svd(F, compute_uv=False)
+        g = oracle.process_fundamental_matrix(F, x0, x1, 3e-2, .9, 1e-3, True)
+        assert abs(g["gate_ratio"] - abs(s[0] - s[1]) / (abs(s[0] + s[1]) / 2)) < 1e-12
+        assert g["success"] == (False if g["gate_ratio"] > 3e-2 else g["success"]) and (g["gate_ratio"] <= 3e-2 or (g["counts4"] == -1).all())

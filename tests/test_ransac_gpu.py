@@ -11,10 +11,17 @@ OPTS = {'required_percent_inliers': .5, 'reprojection_error_allowed': 1e-2, 'fin
         'singular_value_ratio_allowed': 3e-2}
 
 
+def _small_rotation(rng, max_angle=0.3):
+    """Rotation by at most max_angle about a random axis (Rodrigues): keeps a scene in front of both cameras."""
+    a = rng.standard_normal(3)
+    a /= np.linalg.norm(a)
+    th = rng.uniform(-max_angle, max_angle)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
 def _scene(rng, npt=600, noise=2e-3, outliers=7):
-    R, _ = np.linalg.qr(rng.standard_normal((3, 3)))
-    if np.linalg.det(R) < 0:
-        R = -R
+    R = _small_rotation(rng)
     t = rng.standard_normal(3)
     t /= np.linalg.norm(t)
     Xw = np.hstack([rng.standard_normal((npt, 2)), rng.uniform(4, 8, (npt, 1)), np.ones((npt, 1))])
