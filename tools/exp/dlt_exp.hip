@@ -235,6 +235,31 @@ __global__ __launch_bounds__(kDltThreads) void v7_ldsdma(Cameras cam, long long 
     slot = (slot + 1) % NS;
   }
 }
+
+// V8: v4 with non-temporal loads and stores (the stream is touched once: keep it out of the caches)
+template <int WPE>
+__global__ __launch_bounds__(kDltThreads, WPE) void v8_nt(Cameras cam, long long npt, const double *__restrict__ x,
+                                                           const double *__restrict__ xp, double *__restrict__ dst) {
+  const long long stride = (long long)gridDim.x * kDltThreads;
+  long long p = (long long)blockIdx.x * kDltThreads + threadIdx.x;
+  double a0 = 1, a1 = 1, a2 = 1, b0 = 1, b1 = 1, b2 = 1;
+  auto ld = [&](long long q) {
+    a0 = __builtin_nontemporal_load(x + 3 * q); a1 = __builtin_nontemporal_load(x + 3 * q + 1); a2 = __builtin_nontemporal_load(x + 3 * q + 2);
+    b0 = __builtin_nontemporal_load(xp + 3 * q); b1 = __builtin_nontemporal_load(xp + 3 * q + 1); b2 = __builtin_nontemporal_load(xp + 3 * q + 2);
+  };
+  if (p < npt) ld(p);
+  for (; p < npt; p += stride) {
+    const double c0 = a0, c1 = a1, c2 = a2, d0 = b0, d1 = b1, d2 = b2;
+    const long long q = p + stride;
+    if (q < npt) ld(q);
+    double X[4], u, v, up, vp;
+    dlt_solve<true>(cam, c0, c1, c2, d0, d1, d2, X, u, v, up, vp);
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v *o = reinterpret_cast<d2v *>(dst + 4 * p);
+    __builtin_nontemporal_store(d2v{X[0], X[1]}, o);
+    __builtin_nontemporal_store(d2v{X[2], X[3]}, o + 1);
+  }
+}
 }  // namespace
 }  // namespace spv
 using namespace spv;
@@ -307,6 +332,17 @@ int main(int argc, char **argv) {
     timeit(nm, [&] { hipLaunchKernelGGL((v7_ldsdma<4>), dim3(256 * per), dim3(kDltThreads), 4 * 4 * 3072, 0, cam, npt, dx, dxp, dd2); });
   }
   compare("v7<4>");
+  for (int per : {8, 16, 32}) {
+    char nm[64]; snprintf(nm, sizeof nm, "v8 nt ld/st wpe4 %d blk/CU", per);
+    timeit(nm, [&] { hipLaunchKernelGGL((v8_nt<4>), dim3(256 * per), dim3(kDltThreads), 0, 0, cam, npt, dx, dxp, dd2); });
+  }
+  compare("v8<4>");
+  for (int per : {8, 16, 32}) {
+    char nm[64]; snprintf(nm, sizeof nm, "v8 nt ld/st wpe5 %d blk/CU", per);
+    timeit(nm, [&] { hipLaunchKernelGGL((v8_nt<5>), dim3(256 * per), dim3(kDltThreads), 0, 0, cam, npt, dx, dxp, dd2); });
+  }
+  compare("v8<5>");
+  timeit("v0 shipped again", [&] { hipLaunchKernelGGL((dlt_kernel<false>), dim3(256 * 32), dim3(kDltThreads), 0, 0, cam, npt, dx, dxp, dd2); });
   std::vector<double> a(4 * 100000), b(4 * 100000);
   hipMemcpy(a.data(), dd, a.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(b.data(), dd2, b.size() * 8, hipMemcpyDeviceToHost);
   size_t bad = 0; for (size_t i = 0; i < a.size(); i++) bad += a[i] != b[i];
