@@ -48,7 +48,7 @@ constexpr int kThreads = 256;
 constexpr int kTileRows = 64;               // database rows per LDS tile
 constexpr uint32_t kKeyNone = 0xFFFFFFFFu;  // > any real key (dist <= 65280)
 constexpr uint64_t kKey64None = ~0ull;
-constexpr int kMaxGenericDim = 2048;        // generic fallback: 64 queries x dim bytes of LDS
+constexpr int kMaxGenericDim = 2048;        // wide-row kernel: 16 rows x dim bytes of LDS
 
 __device__ __forceinline__ uint32_t sad_hi(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_sad_hi_u8(a, b, c);  // (SAD_U8(a,b) << 16) + c
@@ -267,45 +267,108 @@ __global__ __launch_bounds__(kThreads, 3) void l1k2_tile_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// Generic-width fallback (256 < dim <= 2048): one wave per 64 queries, the queries live
-// transposed in LDS ([dim/4][64] dwords, conflict-free per-lane reads), database rows
-// arrive through wave-uniform scalar loads, 32-bit distance, 64-bit keys.  Correctness
-// path for unusual descriptor widths; the tuned kernels above cover dim <= 256.
+// Wide rows (256 < dim <= 2048, zero padded to a multiple of 128 bytes): a row no longer fits the
+// register file next to a second one, so the roles of the tile kernel are kept but the row is
+// consumed in 128-byte chunks.  A workgroup stages kWideRows database rows (full width) in LDS;
+// for every chunk each lane fetches that chunk of its Q query rows (one 128-byte line per query,
+// L2 resident: the queries of a workgroup are re-read once per database tile), reads the tile's
+// rows by broadcast ds_read_b128 exactly as the tile kernel does, and adds the chunk's SADs into
+// kWideRows x Q accumulators.  After the last chunk the tile's rows enter the running top-2 in
+// ascending row order (strict <, as src/BruteForceNnL1K2.h:129-139).  Distances need more than
+// 16 bits here (2048 x 255), so keys are (32-bit distance, 32-bit index) pairs and the partial
+// result is the merge kernel's 64-bit key.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void l1k2_generic_kernel(const uint32_t *__restrict__ x,
-                                                          const uint32_t *__restrict__ y, int M,
-                                                          int N, int D4, int slice_rows, int S,
-                                                          uint64_t *__restrict__ part) {
-  extern __shared__ uint32_t lq[];  // [D4][64]
-  const int lane = threadIdx.x;
-  const int qi = blockIdx.x * 64 + lane;
-  const int src = min(qi, N - 1);
-  for (int i = 0; i < D4; ++i) lq[i * 64 + lane] = y[(size_t)src * D4 + i];
+constexpr int kWideRows = 16;
+constexpr int kWideChunk4 = 32;  // dwords per chunk
+
+template <int Q>
+__global__ __launch_bounds__(kThreads, 2) void l1k2_wide_kernel(const uint4 *__restrict__ x,
+                                                                const uint4 *__restrict__ y, int M, int N,
+                                                                int D4, int slice_rows, int S,
+                                                                uint64_t *__restrict__ part) {
+  extern __shared__ uint4 wtile[];  // [kWideRows][D4 / 4]
+  const int V4 = D4 / 4;
+  const int t = threadIdx.x;
   const int s = blockIdx.y;
   const int row_begin = s * slice_rows;
   const int row_end = min(M, row_begin + slice_rows);
-  uint64_t k1 = kKey64None, k2 = kKey64None;
-  for (int r = row_begin; r < row_end; ++r) {
-    const uint32_t *xr = x + (size_t)r * D4;  // wave-uniform
-    uint32_t acc = 0;
-    for (int i = 0; i < D4; i += 4) {
-      acc = __builtin_amdgcn_sad_u8(lq[(i + 0) * 64 + lane], xr[i + 0], acc);
-      acc = __builtin_amdgcn_sad_u8(lq[(i + 1) * 64 + lane], xr[i + 1], acc);
-      acc = __builtin_amdgcn_sad_u8(lq[(i + 2) * 64 + lane], xr[i + 2], acc);
-      acc = __builtin_amdgcn_sad_u8(lq[(i + 3) * 64 + lane], xr[i + 3], acc);
+  int qi[Q];
+  const uint4 *yq[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    qi[q] = blockIdx.x * (kThreads * Q) + q * kThreads + t;
+    yq[q] = y + (size_t)min(qi[q], N - 1) * V4;
+  }
+  uint32_t d1[Q], d2[Q], i1[Q], i2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    d1[q] = d2[q] = 0xFFFFFFFFu;
+    i1[q] = i2[q] = 0xFFFFFFFFu;
+  }
+  for (int row0 = row_begin; row0 < row_end; row0 += kWideRows) {
+    const int nrows = min(kWideRows, row_end - row0);
+    __syncthreads();  // the previous tile has been consumed
+    for (int e = t; e < kWideRows * V4; e += kThreads) {
+      const int r = e / V4;
+      wtile[e] = r < nrows ? x[(size_t)(row0 + r) * V4 + (e - r * V4)] : make_uint4(0, 0, 0, 0);
     }
-    const uint64_t k = ((uint64_t)acc << 32) | (uint32_t)r;
-    if (k < k1) {
-      k2 = k1;
-      k1 = k;
-    } else if (k < k2) {
-      k2 = k;
+    __syncthreads();
+    uint32_t acc[kWideRows][Q];
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc[r][q] = 0;
+    for (int c4 = 0; c4 < V4; c4 += kWideChunk4 / 4) {
+      uint32_t qreg[Q][kWideChunk4];
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int v = 0; v < kWideChunk4 / 4; ++v) {
+          const uint4 w = yq[q][c4 + v];
+          qreg[q][4 * v + 0] = w.x;
+          qreg[q][4 * v + 1] = w.y;
+          qreg[q][4 * v + 2] = w.z;
+          qreg[q][4 * v + 3] = w.w;
+        }
+#pragma unroll
+      for (int r = 0; r < kWideRows; ++r) {
+        const uint4 *row = wtile + r * V4 + c4;
+#pragma unroll
+        for (int v = 0; v < kWideChunk4 / 4; ++v) {
+          const uint4 xr = row[v];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[r][q] = __builtin_amdgcn_sad_u8(qreg[q][4 * v + 0], xr.x, acc[r][q]);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[r][q] = __builtin_amdgcn_sad_u8(qreg[q][4 * v + 1], xr.y, acc[r][q]);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[r][q] = __builtin_amdgcn_sad_u8(qreg[q][4 * v + 2], xr.z, acc[r][q]);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[r][q] = __builtin_amdgcn_sad_u8(qreg[q][4 * v + 3], xr.w, acc[r][q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r) {
+      if (r < nrows) {  // workgroup-uniform
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const uint32_t d = acc[r][q], idx = (uint32_t)(row0 + r);
+          const bool lt2 = d < d2[q], lt1 = d < d1[q];
+          d2[q] = lt1 ? d1[q] : (lt2 ? d : d2[q]);
+          i2[q] = lt1 ? i1[q] : (lt2 ? idx : i2[q]);
+          d1[q] = lt1 ? d : d1[q];
+          i1[q] = lt1 ? idx : i1[q];
+        }
+      }
     }
   }
-  if (qi < N) {
-    uint64_t *dst = part + ((size_t)qi * S + s) * 2;
-    dst[0] = k1;
-    dst[1] = k2;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (qi[q] < N) {
+      uint64_t *dst = part + ((size_t)qi[q] * S + s) * 2;
+      dst[0] = i1[q] == 0xFFFFFFFFu ? kKey64None : (((uint64_t)d1[q] << 32) | i1[q]);
+      dst[1] = i2[q] == 0xFFFFFFFFu ? kKey64None : (((uint64_t)d2[q] << 32) | i2[q]);
+    }
   }
 }
 
@@ -412,16 +475,16 @@ static int pick_dim_pad(int dim) {
   static const int kDims[] = {64, 128, 144, 192, 256};
   for (int d : kDims)
     if (dim <= d) return d;
-  return dim <= kMaxGenericDim ? dim : -1;  // generic fallback kernel, no padding
+  return dim <= kMaxGenericDim ? (dim + 127) / 128 * 128 : -1;  // wide-row kernel: whole 128-byte chunks
 }
 
 L1K2Plan l1k2_plan(int xrows, int yrows, int dim) {
   L1K2Plan p{};
   p.dim_pad = pick_dim_pad(dim);
   if (p.dim_pad < 0 || xrows < 0 || yrows < 0) return p;
-  const bool generic = p.dim_pad > 256;
-  const int qmax = generic ? 1 : max_q_for(p.dim_pad);
-  const int qlanes = generic ? 64 : kThreads;  // queries per workgroup per unit of q
+  const bool wide = p.dim_pad > 256;
+  const int qmax = wide ? 2 : max_q_for(p.dim_pad);
+  const int qlanes = kThreads;  // queries per workgroup per unit of q
   // queries per lane: as many as registers allow once there are enough queries
   // to keep >= 512 workgroups of 256 lanes busy without it
   // as many queries per lane as registers allow, unless that leaves too few workgroups
@@ -429,7 +492,7 @@ L1K2Plan l1k2_plan(int xrows, int yrows, int dim) {
   int q = qmax;
   while (q > 1) {
     const long long qb = ((long long)yrows + qlanes * q - 1) / (qlanes * q);
-    const long long smax = std::max<long long>(1, xrows / kTileRows);
+    const long long smax = std::max<long long>(1, xrows / (wide ? kWideRows : kTileRows));
     if (qb * smax >= 1024) break;
     q /= 2;
   }
@@ -503,15 +566,18 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
     case 192: launch_tile_q<48>(kx, ky, xrows, yrows, p, part, stream); break;
     case 256: launch_tile_q<64>(kx, ky, xrows, yrows, p, part, stream); break;
     default: {
-      if (p.dim_pad <= 256 || p.dim_pad > kMaxGenericDim)
+      if (p.dim_pad <= 256 || p.dim_pad > kMaxGenericDim || p.dim_pad % 128)
         return set_error(SPV_ERR_INVALID, "internal: bad dim_pad %d", p.dim_pad);
-      const size_t lds = (size_t)64 * p.dim_pad;
-      SPV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(l1k2_generic_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(l1k2_generic_kernel, dim3(p.qblocks, p.slices), dim3(64), lds, stream,
-                         reinterpret_cast<const uint32_t *>(kx),
-                         reinterpret_cast<const uint32_t *>(ky), xrows, yrows, p.dim_pad / 4,
-                         p.slice_rows, p.slices, part);
+      const size_t lds = (size_t)kWideRows * p.dim_pad;
+      const dim3 grid(p.qblocks, p.slices);
+      if (p.q >= 2)
+        hipLaunchKernelGGL((l1k2_wide_kernel<2>), grid, dim3(kThreads), lds, stream,
+                           reinterpret_cast<const uint4 *>(kx), reinterpret_cast<const uint4 *>(ky), xrows, yrows,
+                           p.dim_pad / 4, p.slice_rows, p.slices, part);
+      else
+        hipLaunchKernelGGL((l1k2_wide_kernel<1>), grid, dim3(kThreads), lds, stream,
+                           reinterpret_cast<const uint4 *>(kx), reinterpret_cast<const uint4 *>(ky), xrows, yrows,
+                           p.dim_pad / 4, p.slice_rows, p.slices, part);
     }
   }
   }
