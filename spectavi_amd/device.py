@@ -244,3 +244,46 @@ def profile_read(name):
     ms = ct.c_double(0.0)
     check(clib.spv_profile_read(name.encode(), ct.byref(n), ct.byref(ms)))
     return int(n.value), float(ms.value)
+
+
+clib.spv_ransac_workspace_bytes.restype = ct.c_size_t
+clib.spv_ransac_workspace_bytes.argtypes = [ct.c_int, ct.c_longlong, ct.c_int]
+clib.spv_ransac_process_candidates_device.restype = ct.c_int
+clib.spv_ransac_process_candidates_device.argtypes = [_vp, ct.c_int, ct.c_longlong, _vp, _vp, ct.c_double, ct.c_double,
+                                                      ct.c_double, ct.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                      _vp, ct.c_size_t, _vp]
+
+
+def ransac_process_candidates(Fs, x0, x1, singular_value_ratio_allowed=3e-2, required_percent_inliers=.9,
+                              reprojection_error_allowed=.5, find_best_even_in_failure=True, want_mask=False,
+                              workspace=None):
+    """RANSAC candidate processing on device (reference src/RansacFitter.h:42-95 for a batch of
+    candidates): Fs CUDA float64 [nF,3,3] (nF <= 16383), x0, x1 CUDA float64 [npt,3].  Returns a dict of
+    CUDA tensors: success int32 [nF], inlier_count int32 [nF], best_camera int32 [nF], camera float64
+    [nF,3,4], singular_value_ratio float64 [nF], essential float64 [nF,3,3], counts4 int32 [nF,4] and,
+    with want_mask, inlier_mask uint8 [nF,npt].  Asynchronous on the current stream."""
+    _need(Fs, torch.float64, "Fs")
+    _need(x0, torch.float64, "x0")
+    _need(x1, torch.float64, "x1")
+    nF, npt = Fs.shape[0], x0.shape[0]
+    assert Fs.shape[1:] == (3, 3) and x0.shape == x1.shape and x0.shape[1] == 3
+    dev = x0.device
+    out = {"success": torch.empty(nF, dtype=torch.int32, device=dev),
+           "inlier_count": torch.empty(nF, dtype=torch.int32, device=dev),
+           "best_camera": torch.empty(nF, dtype=torch.int32, device=dev),
+           "camera": torch.empty((nF, 3, 4), dtype=torch.float64, device=dev),
+           "singular_value_ratio": torch.empty(nF, dtype=torch.float64, device=dev),
+           "essential": torch.empty((nF, 3, 3), dtype=torch.float64, device=dev),
+           "counts4": torch.empty((nF, 4), dtype=torch.int32, device=dev)}
+    mask = torch.empty((nF, npt), dtype=torch.uint8, device=dev) if want_mask else None
+    with _on_device_of(Fs, x0, x1) as stream:
+        ws = (workspace or _default_ws).get(clib.spv_ransac_workspace_bytes(nF, npt, 1 if want_mask else 0), dev)
+        check(clib.spv_ransac_process_candidates_device(
+            Fs.data_ptr(), nF, npt, x0.data_ptr(), x1.data_ptr(), float(singular_value_ratio_allowed),
+            float(required_percent_inliers), float(reprojection_error_allowed), int(bool(find_best_even_in_failure)),
+            out["success"].data_ptr(), out["inlier_count"].data_ptr(), out["best_camera"].data_ptr(),
+            out["camera"].data_ptr(), out["singular_value_ratio"].data_ptr(), out["essential"].data_ptr(),
+            out["counts4"].data_ptr(), mask.data_ptr() if want_mask else None, ws.data_ptr(), ws.numel(), stream))
+    if want_mask:
+        out["inlier_mask"] = mask
+    return out
