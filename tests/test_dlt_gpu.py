@@ -175,3 +175,27 @@ def test_many_camera_pairs(oracle):
         dc.check_definition(X, P0, P1, x, xp, err=e, what="pair %d" % k)
         dc.check_against_oracle(X, oracle.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp, what="pair %d" % k)
     assert worst == 0.0
+
+
+def test_large_host_call_is_chunked_and_pipelined(oracle):
+    """Results of 16 MB and more leave through the chunked upload / solve / download pipeline
+    (pinned bounce buffers drained by host threads): 2 300 017 points = three chunks, the last one
+    ragged; fresh and reused output arrays; both entry points; bit for bit the mirror's rows."""
+    from spectavi_amd import mvg
+    from spectavi_amd.mvg import _dlt_triangulate
+    rng = np.random.default_rng(41)
+    npt = 2_300_017
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((npt, 4))
+    x = Xw @ P0.T + rng.normal(0, 1e-3, (npt, 3))
+    xp = Xw @ P1.T + rng.normal(0, 1e-3, (npt, 3))
+    want = oracle.dlt_mirror_triangulate(P0, P1, x, xp)
+    X = mvg.dlt_triangulate(P0, P1, x, xp)
+    assert np.array_equal(X, want)
+    dst = np.full((npt, 4), np.nan)
+    _dlt_triangulate(P0, P1, npt, x, xp, dst)          # into an array that already has its pages
+    assert np.array_equal(dst, want)
+    e = mvg.dlt_reprojection_error(P0, P1, x, xp)       # 18 MB of errors: pipelined too
+    assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp))
+    sub = rng.integers(0, npt, 20000)
+    dc.check_definition(X[sub], P0, P1, x[sub], xp[sub], err=e[sub], what="large host call")

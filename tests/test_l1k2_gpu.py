@@ -237,3 +237,20 @@ def test_config5_full_shard(oracle):
     oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y[sub].cpu().numpy(), nthreads=oracle.max_threads())
     assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
     assert np.array_equal(dist[sub].cpu().numpy(), odist)
+
+
+def test_large_host_output_uses_the_pinned_pipeline(oracle):
+    """1.2M queries: the 19 MB index array comes back through the pinned, threaded download path
+    (results of 16 MB and more); a strided sample against the oracle, every row against the
+    device-resident path."""
+    import torch
+    from spectavi_amd import device
+    rng = np.random.default_rng(99)
+    x = rng.integers(0, 256, (513, 128), dtype=np.uint8)
+    y = rng.integers(0, 256, (1_200_003, 128), dtype=np.uint8)
+    idx, dist = _raw(x, y)
+    didx, ddist = device.l1k2(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    assert np.array_equal(idx, didx.cpu().numpy().view(np.uint64)) and np.array_equal(dist, ddist.cpu().numpy())
+    sub = np.arange(0, y.shape[0], 1013)
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y[sub], nthreads=8)
+    assert np.array_equal(idx[sub], oidx) and np.array_equal(dist[sub], odist)
