@@ -298,32 +298,17 @@ typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaChunk = kMfmaChunkC;  // dims per step: 8 lanes x 16 B = one full 128-byte line per row
 
-// Epilogue shared by the matrix-core projection kernels: the wave's 4 x CT accumulator tiles are
-// transposed through its LDS tile so that lane l holds the n*m projections of row row0 + l, then
-// sign codes, the g least-confident bits and the bucket histogram as in the VALU kernel.  Rows at
-// and past row_limit are not written.
-template <int CT, bool IS_QUERY, int GMAX>
-__device__ __forceinline__ void project_mfma_epilogue(
-    const mfma_f4 (&acc)[4][CT], float *ws, int lane, long long row0, long long row_limit, long long nrows_total,
+// Row part of the matrix-core projection kernels' epilogue: lane l holds the n*m projections of row
+// row0 + l at `mine` (LDS, column c = table*m + bit; column `pad` is a harmless filler for the slots
+// past m): sign codes, the g least-confident bits and the bucket histogram as in the VALU kernel.
+// Rows at and past row_limit are not written.
+template <bool IS_QUERY, int GMAX>
+__device__ __forceinline__ void project_rows_epilogue(
+    const float *mine, int pad, int lane, long long row0, long long row_limit, long long nrows_total,
     int m, int n, int g, uint32_t *__restrict__ codes, uint32_t *__restrict__ masks,
     uint32_t *__restrict__ counts, uint32_t *__restrict__ ranks, uint32_t hbmask, int nb) {
-  constexpr int NC = 16 * CT;
-  constexpr int ES = NC + 1;
-  const int r16 = lane & 15, q4 = lane >> 4;
-  // transpose: D tile element v of lane (r16, q4) is row 16*rt + 4*q4 + v, column 16*ct + r16
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) ws[(16 * rt + 4 * q4 + v) * ES + 16 * ct + r16] = acc[rt][ct][v];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
   const long long r = row0 + lane;
   const long long nrows = row_limit;  // rows at and past it belong to nobody here
-  const float *mine = ws + lane * ES;
   for (int j = 0; j < n; ++j) {
     uint32_t code = 0;
     float best[GMAX];
@@ -338,7 +323,7 @@ __device__ __forceinline__ void project_mfma_epilogue(
     for (int b0 = 0; b0 < m; b0 += 8) {
       float p8[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) p8[i] = mine[min(j * m + b0 + i, NC)];
+      for (int i = 0; i < 8; ++i) p8[i] = mine[min(j * m + b0 + i, pad)];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int b = b0 + i;
@@ -376,6 +361,30 @@ __device__ __forceinline__ void project_mfma_epilogue(
       if (r < nrows) masks[(size_t)j * nrows_total + r] = mask;
     }
   }
+}
+
+// Epilogue of project_mfma_kernel: the wave's 4 x CT accumulator tiles are transposed through its LDS
+// tile so that lane l holds the projections of row row0 + l, then the row part above.
+template <int CT, bool IS_QUERY, int GMAX>
+__device__ __forceinline__ void project_mfma_epilogue(
+    const mfma_f4 (&acc)[4][CT], float *ws, int lane, long long row0, long long row_limit, long long nrows_total,
+    int m, int n, int g, uint32_t *__restrict__ codes, uint32_t *__restrict__ masks,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ ranks, uint32_t hbmask, int nb) {
+  constexpr int NC = 16 * CT;
+  constexpr int ES = NC + 1;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  // transpose: D tile element v of lane (r16, q4) is row 16*rt + 4*q4 + v, column 16*ct + r16
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ws[(16 * rt + 4 * q4 + v) * ES + 16 * ct + r16] = acc[rt][ct][v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  project_rows_epilogue<IS_QUERY, GMAX>(ws + lane * ES, NC, lane, row0, row_limit, nrows_total, m, n, g, codes, masks,
+                                        counts, ranks, hbmask, nb);
 }
 
 template <int CT, bool IS_QUERY, int GMAX, bool FULL>
@@ -487,6 +496,149 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 
 
   project_mfma_epilogue<CT, IS_QUERY, GMAX>(acc, ws, lane, row0, nrows, nrows, m, n, g, codes, masks, counts, ranks,
                                             hbmask, nb);
+}
+
+// The same projection when n*m is not a whole number of 16-column tiles and 1..8 columns are left
+// over (the default configuration: n*m = 2 x 17 = 34 = two tiles + 2): the left-over columns go
+// through v_mfma_f32_4x4x1_16B_f32 -- 16 blocks of D[4x4] += A[4x1] B[1x4], i.e. 64 rows x 4 columns
+// x ONE k per instruction at ~11 cycles per SIMD -- instead of a third, 7/8-empty 16-column tile at
+// 32 cycles per 4 k and 16 rows (measured, tools/exp/mfma_4x4_exp.hip: lane l feeds A[row l] and
+// B[column l % 4], D[i] of lane l is row 4 (l / 4) + i, column l % 4; 51 200 of 51 200 outputs equal the
+// std::fmaf chain in k order).  -21 % matrix-pipe time per row at n*m = 34.  Differences from
+// project_mfma_kernel besides that: whole-chunk dims only (dim % 32 == 0, dim <= 512; anything else
+// takes project_mfma_kernel, as does SPECTAVI_CASCADE_MFMA4=0 for A/B runs); staged rows
+// are 16-byte aligned (36 floats: one ds_write_b128 per load, one ds_read_b128 per k-step for the
+// 4x4x1 A operand); the left-over hyperplanes sit in a workgroup-shared LDS table [dim/4][4][4].
+template <int CT, int NG, bool IS_QUERY, int GMAX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void project_mfma4_kernel(
+    const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
+    const float *__restrict__ dictm,     // [dim][NCD], column = table*m + bit, zero padded; NCD = 16*(CT+1)
+    uint32_t *__restrict__ codes, uint32_t *__restrict__ masks, uint8_t *__restrict__ u8img,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ ranks, uint32_t hbmask, int nb) {
+  constexpr int NCD = 16 * (CT + 1);     // row length of dictm (the layout the 16-column kernel uses)
+  constexpr int NCOL = 16 * CT + 4 * NG; // columns computed here
+  constexpr int KS = kMfmaChunk / 4;
+  constexpr int NX = kMfmaChunk / 4;
+  constexpr int XS = kMfmaChunk + 4;     // floats per staged row: 16-byte aligned rows
+  constexpr int ES = NCOL + 1;           // floats per row of the transposed projections
+  constexpr int kWaveFloats = 64 * (ES > XS ? ES : XS);
+  constexpr int kMaxDim = 512;
+  __shared__ __attribute__((aligned(16))) float lds[(kThreads / 64) * kWaveFloats];
+  __shared__ __attribute__((aligned(16))) float hl[NG][kMaxDim / 4][4][4];  // [group][k / 4][column][k % 4]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *ws = lds + wv * kWaveFloats;
+  // left-over hyperplanes -> LDS (whole workgroup; the only workgroup-level step)
+  for (int e = threadIdx.x; e < NG * dim * 4; e += kThreads) {
+    const int gq = e / (dim * 4), rem = e - gq * dim * 4;
+    const int k = rem >> 2, j = rem & 3;
+    hl[gq][k >> 2][j][k & 3] = dictm[(size_t)k * NCD + 16 * CT + 4 * gq + j];
+  }
+  __syncthreads();
+  const long long row0 = ((long long)blockIdx.x * (kThreads / 64) + wv) * 64;
+  if (row0 >= nrows) return;  // whole wave past the end (nothing below synchronises across waves)
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int quad = lane & 3;
+
+  mfma_f4 acc[4][CT > 0 ? CT : 1];
+  mfma_f4 accl[NG];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) accl[gq] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+  float4 px[NX];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = lane + 64 * j;  // (row of the tile, 4-dim part of the step): 8 lanes per row
+      const long long grow = min(row0 + (e >> 3), (long long)nrows - 1);
+      const mfma_f4 t4 = __builtin_nontemporal_load(reinterpret_cast<const mfma_f4 *>(rows + (size_t)grow * dim + c0 + 4 * (e & 7)));
+      px[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+    }
+  };
+  // operands of the 16-column tiles for a whole chunk, requested ahead of the next row prefetch
+  // (see project_mfma_kernel)
+  float bq[KS][CT > 0 ? CT : 1];
+  auto fetch_b_chunk = [&](int c0) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) bq[ks][ct] = dictm[(size_t)(c0 + 4 * ks + q4) * NCD + 16 * ct + r16];
+  };
+  prefetch(0);
+  fetch_b_chunk(0);
+  for (int c0 = 0; c0 < dim; c0 += kMfmaChunk) {
+    uint4 keep = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = lane + 64 * j;
+      const int row = e >> 3, part = e & 7;
+      const float4 v = px[j];
+      *reinterpret_cast<float4 *>(ws + row * XS + 4 * part) = v;
+      const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
+      const uint32_t g0 = __builtin_amdgcn_mov_dpp(pk, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
+      const uint32_t g1 = __builtin_amdgcn_mov_dpp(pk, 0x55, 0xF, 0xF, true);  // [1,1,1,1]
+      const uint32_t g2 = __builtin_amdgcn_mov_dpp(pk, 0xAA, 0xF, 0xF, true);  // [2,2,2,2]
+      const uint32_t g3 = __builtin_amdgcn_mov_dpp(pk, 0xFF, 0xF, 0xF, true);  // [3,3,3,3]
+      if (quad == (j & 3)) keep = make_uint4(g0, g1, g2, g3);
+      if ((j & 3) == 3) {
+        const int krow = 8 * ((j & ~3) + quad) + (lane >> 3);  // row of the load this lane kept
+        const int kbyte = c0 + 16 * ((lane & 7) >> 2);         // first byte of the quad's 16
+        if (row0 + krow < nrows)
+          *reinterpret_cast<uint4 *>(u8img + (size_t)(row0 + krow) * dim + kbyte) = keep;
+      }
+    }
+    if (c0 + kMfmaChunk < dim) prefetch(c0 + kMfmaChunk);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // left-over columns first in program order (any order is fine: separate accumulators)
+      const float4 al = *reinterpret_cast<const float4 *>(ws + lane * XS + 4 * ks);  // row = lane, 4 consecutive k
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const float4 bl = *reinterpret_cast<const float4 *>(&hl[gq][(c0 >> 2) + ks][quad][0]);
+        accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.x, bl.x, accl[gq], 0, 0, 0);
+        accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.y, bl.y, accl[gq], 0, 0, 0);
+        accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.z, bl.z, accl[gq], 0, 0, 0);
+        accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.w, bl.w, accl[gq], 0, 0, 0);
+      }
+      if constexpr (CT > 0) {
+        float a[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) a[rt] = ws[(16 * rt + r16) * XS + 4 * ks + q4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], bq[ks][ct], acc[rt][ct], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c0 + kMfmaChunk < dim) fetch_b_chunk(c0 + kMfmaChunk);
+  }
+  // transpose to one row per lane: 16-column tiles (D element v of lane (r16, q4) is row
+  // 16 rt + 4 q4 + v, column 16 ct + r16), then the 4-column groups (D[i] of lane l is row
+  // 4 (l / 4) + i, column l % 4)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ws[(16 * rt + 4 * q4 + v) * ES + 16 * ct + r16] = acc[rt][ct][v];
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ws[(4 * (lane >> 2) + i) * ES + 16 * CT + 4 * gq + quad] = accl[gq][i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  project_rows_epilogue<IS_QUERY, GMAX>(ws + lane * ES, NCOL, lane, row0, nrows, nrows, m, n, g, codes, masks, counts,
+                                        ranks, hbmask, nb);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1040,6 +1192,35 @@ void launch_project_mfma(int g, const float *rows, int nrows, int dim, int m, in
   const dim3 grid((nrows + kThreads - 1) / kThreads), block(kThreads);
   constexpr int G0 = IS_QUERY ? 2 : 1, G1 = IS_QUERY ? 4 : 1, G2 = IS_QUERY ? 16 : 1;
   const bool full = dim % kMfmaChunk == 0;
+  // 1..8 columns beyond whole 16-column tiles (the default 2 x 17): left-over columns on 4x4x1 MFMAs
+  {
+    const int nm = n * m, ctm = nm / 16, left = nm % 16, ng = (left + 3) / 4;
+    static const bool off4 = [] {
+      const char *e = getenv("SPECTAVI_CASCADE_MFMA4");
+      return e && e[0] == '0';
+    }();
+    if (!off4 && full && dim <= 512 && left >= 1 && left <= 8) {
+#define SPV_LAUNCH_M4(CTV, NGV)                                                                        \
+  if (g <= G0)                                                                                         \
+    hipLaunchKernelGGL((project_mfma4_kernel<CTV, NGV, IS_QUERY, G0>), grid, block, 0, stream, rows,   \
+                       nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb);      \
+  else                                                                                                 \
+    hipLaunchKernelGGL((project_mfma4_kernel<CTV, NGV, IS_QUERY, G2>), grid, block, 0, stream, rows,   \
+                       nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb)
+      switch (ctm * 2 + (ng - 1)) {
+        case 0: SPV_LAUNCH_M4(0, 1); break;
+        case 1: SPV_LAUNCH_M4(0, 2); break;
+        case 2: SPV_LAUNCH_M4(1, 1); break;
+        case 3: SPV_LAUNCH_M4(1, 2); break;
+        case 4: SPV_LAUNCH_M4(2, 1); break;
+        case 5: SPV_LAUNCH_M4(2, 2); break;
+        case 6: SPV_LAUNCH_M4(3, 1); break;
+        default: SPV_LAUNCH_M4(3, 2); break;
+      }
+#undef SPV_LAUNCH_M4
+      return;
+    }
+  }
 #define SPV_LAUNCH_ONE(CTV, GV, FULLV)                                                               \
   hipLaunchKernelGGL((project_mfma_kernel<CTV, IS_QUERY, GV, FULLV>), grid, block, 0, stream, rows,  \
                      nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb)

@@ -40,6 +40,39 @@ def test_matches_oracle(oracle, m_rows, n_rows, dim, m, n, g):
     assert np.array_equal(idx, oidx)
 
 
+@pytest.mark.parametrize("dim,m,n,g", [
+    # n*m = 16 CT + left, left in 1..8: the left-over columns run on 4x4x1 MFMAs (project_mfma4_kernel<CT,NG>)
+    (128, 2, 1, 1),    # CT 0, one group
+    (64, 6, 1, 2),     # CT 0, two groups
+    (128, 9, 2, 2),    # 18 = 16 + 2
+    (256, 11, 2, 4),   # 22 = 16 + 6: two groups, g > 2 (the 16-entry selection network)
+    (128, 17, 2, 2),   # 34 = 32 + 2: the default configuration of a 1M-row database
+    (512, 13, 3, 2),   # 39 = 32 + 7, widest rows the kernel takes
+    (32, 25, 2, 3),    # 50 = 48 + 2, m > bucket bits
+    (128, 14, 4, 0),   # 56 = 48 + 8, no probing at all
+    # the same column counts where that kernel does not apply: ragged chunk, rows wider than 512
+    (144, 17, 2, 2), (544, 9, 2, 2),
+])
+def test_left_over_hyperplane_columns(oracle, dim, m, n, g):
+    """Column counts that are not a whole number of 16-column MFMA tiles, on every (tiles, groups)
+    instantiation of the 4x4x1 path and on its fall-backs: codes, masks and therefore candidates,
+    indices and distances bit-identical to the oracle; non-integer inputs included (the uint8 image
+    truncates, the projections do not)."""
+    from spectavi_amd import feature
+    rng = np.random.default_rng([dim, m, n, g])
+    x = rng.integers(-128, 128, (3000, dim)).astype(np.float32)
+    y = rng.integers(-128, 128, (1100, dim)).astype(np.float32)
+    y[:500] = np.clip(x[rng.integers(0, 3000, 500)] + rng.integers(-2, 3, (500, dim)), -128, 127)
+    x[100:200] += rng.uniform(-0.49, 0.49, (100, dim)).astype(np.float32)
+    y[600:700] += rng.uniform(-0.49, 0.49, (100, dim)).astype(np.float32)
+    d = rng.standard_normal((n, dim, m)).astype(np.float32)
+    idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(x, y, m, n, g, d)
+    assert np.array_equal(ncand, oncand)
+    assert np.array_equal(dist, odist)
+    assert np.array_equal(idx, oidx)
+
+
 @pytest.mark.parametrize("m_rows,n_rows,dim,m,n,g,span", [
     (2, 1350, 128, 6, 3, 4, 20), (300, 900, 64, 8, 2, 5, 2), (1000, 500, 32, 11, 3, 3, 20), (64, 64, 16, 4, 1, 2, 2),
 ])
