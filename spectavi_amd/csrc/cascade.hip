@@ -509,8 +509,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 
 // takes project_mfma_kernel, as does SPECTAVI_CASCADE_MFMA4=0 for A/B runs); staged rows
 // are 16-byte aligned (36 floats: one ds_write_b128 per load, one ds_read_b128 per k-step for the
 // 4x4x1 A operand); the left-over hyperplanes sit in a workgroup-shared LDS table [dim/4][4][4].
+// workgroups per CU by LDS (4 wave tiles + the left-over table): three for the default shape
+constexpr int mfma4_waves_per_simd(int ct, int ng) {
+  return 4 * 64 * 4 * (16 * ct + 4 * ng + 1 > 36 ? 16 * ct + 4 * ng + 1 : 36) + ng * 8192 <= 160 * 1024 / 3 ? 3 : 2;
+}
+
 template <int CT, int NG, bool IS_QUERY, int GMAX>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void project_mfma4_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(mfma4_waves_per_simd(CT, NG)))) void project_mfma4_kernel(
     const float *__restrict__ rows, int nrows, int dim, int m, int n, int g,
     const float *__restrict__ dictm,     // [dim][NCD], column = table*m + bit, zero padded; NCD = 16*(CT+1)
     uint32_t *__restrict__ codes, uint32_t *__restrict__ masks, uint8_t *__restrict__ u8img,
