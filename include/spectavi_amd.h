@@ -75,13 +75,17 @@ int spv_set_devices(const int *devices, int count);
  *                     (a clique of one).  Kernel names for spv_profile_read: "gather",
  *                     "gather_widen".  librccl is opened on first use (SPECTAVI_RCCL_LIB overrides
  *                     the name).
+ *   SPV_GATHER_PEERCOPY the same records, the same root layout and widening kernel, moved with one
+ *                     hipMemcpyPeerAsync per device instead of RCCL (no librccl in the process;
+ *                     accepts a device listed more than once).
  *   SPV_GATHER_DIRECT every shard is copied straight into its slice of the caller's arrays; no
  *                     collective.
- *   SPV_GATHER_AUTO   (default) environment SPECTAVI_GATHER = "rccl" | "direct" if set, else RCCL
- *                     exactly when more than one distinct device is configured. */
+ *   SPV_GATHER_AUTO   (default) environment SPECTAVI_GATHER = "rccl" | "copy" | "direct" if set,
+ *                     else RCCL exactly when more than one distinct device is configured. */
 #define SPV_GATHER_AUTO (-1)
 #define SPV_GATHER_DIRECT 0
 #define SPV_GATHER_RCCL 1
+#define SPV_GATHER_PEERCOPY 2
 int spv_set_gather_mode(int mode);
 /* Host statement of the 16-byte record format (no GPU involved), for callers that run their own
  * collective on raw records.  pack: idx uint64[n,2] ((size_t)-1 = no neighbour), dist32 = int32 or

@@ -101,14 +101,14 @@ def set_hash_seed(seed=None):
         clib.spv_set_hash_seed(int(seed) & 0xFFFFFFFF, 1)
 
 
-GATHER_AUTO, GATHER_DIRECT, GATHER_RCCL = -1, 0, 1
+GATHER_AUTO, GATHER_DIRECT, GATHER_RCCL, GATHER_PEERCOPY = -1, 0, 1, 2
 
 
 def set_gather_mode(mode):
     """How multi-device host-array calls collect their shards: "rccl" (ncclGather of 16-byte records
-    on the first listed GPU, inside libspectavi.so), "direct" (each shard copied to its slice), or
+    on the first listed GPU, inside libspectavi.so), "copy" (the same records and root layout moved by peer copies, no RCCL), "direct" (each shard copied to its slice), or
     "auto" (SPECTAVI_GATHER if set, else RCCL when more than one distinct device is listed)."""
-    mode = {"auto": GATHER_AUTO, "direct": GATHER_DIRECT, "rccl": GATHER_RCCL}.get(mode, mode)
+    mode = {"auto": GATHER_AUTO, "direct": GATHER_DIRECT, "rccl": GATHER_RCCL, "copy": GATHER_PEERCOPY}.get(mode, mode)
     clib.spv_set_gather_mode.restype = ct.c_int
     clib.spv_set_gather_mode.argtypes = [ct.c_int]
     check(clib.spv_set_gather_mode(int(mode)))

@@ -201,7 +201,7 @@ static std::vector<int> device_list() {
 // into its slice (direct), or gathered on the first listed GPU over RCCL and copied from there
 // (north_star's "RCCL gather of (idx0, idx1, d0, d1)").  spv_set_gather_mode / SPECTAVI_GATHER
 // choose; left alone, RCCL is used exactly when more than one distinct device is configured.
-static bool use_rccl_gather(const std::vector<int> &devs) {
+static int gather_transport(const std::vector<int> &devs) {
   int mode;
   {
     std::lock_guard<std::mutex> lk(g_cfg_mutex);
@@ -211,14 +211,16 @@ static bool use_rccl_gather(const std::vector<int> &devs) {
     const char *e = getenv("SPECTAVI_GATHER");
     if (e && !strcmp(e, "rccl")) mode = SPV_GATHER_RCCL;
     if (e && !strcmp(e, "direct")) mode = SPV_GATHER_DIRECT;
+    if (e && !strcmp(e, "copy")) mode = SPV_GATHER_PEERCOPY;
   }
-  if (mode >= 0) return mode == SPV_GATHER_RCCL;
-  if (devs.size() < 2) return false;
+  if (mode >= 0) return mode;
+  if (devs.size() < 2) return SPV_GATHER_DIRECT;
   for (size_t a = 0; a < devs.size(); ++a)
     for (size_t b = a + 1; b < devs.size(); ++b)
-      if (devs[a] == devs[b]) return false;  // a clique needs distinct devices
-  return true;
+      if (devs[a] == devs[b]) return SPV_GATHER_DIRECT;  // a clique needs distinct devices
+  return SPV_GATHER_RCCL;
 }
+static bool use_rccl_gather(const std::vector<int> &devs) { return gather_transport(devs) != SPV_GATHER_DIRECT; }
 
 int ensure_device() { return use_device(device_list()[0]); }
 
@@ -995,7 +997,7 @@ int run_gathered(const std::vector<int> &all_devs, long long total, const std::v
   std::lock_guard<std::mutex> lk(gather_mutex());  // one clique user at a time
   for (int d : devs) SPV_TRY(use_device(d));         // fail early on a bad device number
   GatherCtx *ctx = nullptr;
-  SPV_TRY(gather_ctx_get(devs, &ctx));
+  SPV_TRY(gather_ctx_get(devs, gather_transport(all_devs) == SPV_GATHER_RCCL, &ctx));
   const long long max_cnt = shard_lo(total, G, 1);   // = size of shard 0, the largest
   std::vector<BufList> bufs(G + 1);                  // [G] = the root's receive / staging buffers
   std::vector<std::vector<const void *>> send(K, std::vector<const void *>(G, nullptr));
@@ -1274,7 +1276,7 @@ int spv_set_devices(const int *devices, int count) {
 
 int spv_set_gather_mode(int mode) {
   clear_error();
-  if (mode != SPV_GATHER_AUTO && mode != SPV_GATHER_DIRECT && mode != SPV_GATHER_RCCL)
+  if (mode != SPV_GATHER_AUTO && mode != SPV_GATHER_DIRECT && mode != SPV_GATHER_RCCL && mode != SPV_GATHER_PEERCOPY)
     return set_error(SPV_ERR_INVALID, "gather mode %d", mode);
   std::lock_guard<std::mutex> lk(g_cfg_mutex);
   g_gather_mode = mode;

@@ -94,11 +94,12 @@ int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigne
 // ---- multi-device result gather over RCCL (gather.hip) -------------------------------
 struct GatherCtx;                    // communicator clique + one stream per rank, cached per device list
 std::mutex &gather_mutex();          // held by the caller around every use of a clique
-int gather_ctx_get(const std::vector<int> &devs, GatherCtx **out);
+int gather_ctx_get(const std::vector<int> &devs, bool use_rccl, GatherCtx **out);
 hipStream_t gather_stream(GatherCtx *ctx, int rank);
 // (idx uint64[cnt,2], 32-bit dist[cnt,2]) -> cnt 16-byte records (records.h)
 int gather_pack_run(const uint64_t *d_idx, const void *d_d32, long long cnt, void *d_rec, hipStream_t stream);
-// ncclGather of bytes_per_rank bytes from every rank's d_send[r] into d_recv_root on rank 0
+// bytes_per_rank bytes from every rank's d_send[r] into slot r of d_recv_root on rank 0: ncclGather, or
+// (peer-copy transport) one hipMemcpyPeerAsync per rank
 int gather_bytes_run(GatherCtx *ctx, const std::vector<const void *> &d_send, void *d_recv_root,
                      size_t bytes_per_rank);
 // [G][max_cnt] records -> the ABI layout over all `total` rows

@@ -7,7 +7,10 @@
 // (spv_set_devices / SPECTAVI_DEVICES with SPECTAVI_GATHER=rccl): one communicator clique from
 // ncclCommInitAll (cached per device list), one ncclGather per rank inside a group call, then on
 // the root one widening kernel into the ABI layout (size_t idx[N,2], 32-bit dist[N,2]) and one
-// copy to the caller's arrays.  The one-process-per-GPU form of the same exchange is
+// copy to the caller's arrays.  A second transport, SPECTAVI_GATHER=copy, moves the same blocks
+// into the same root layout with hipMemcpyPeerAsync (no RCCL in the process; also the only
+// gathering transport that accepts a device listed twice, which is how the multi-rank layout --
+// ragged shards, padding, rank order -- is exercised on a one-GPU box).  The one-process-per-GPU form of the same exchange is
 // spectavi_amd/sharded.py (torch.distributed, backend nccl = RCCL).
 //
 // librccl is ~570 MB: it is opened on first use (dlopen by soname, so a copy already mapped by
@@ -81,15 +84,18 @@ int rccl_load() {
 
 }  // namespace
 
-// One communicator per listed device (rank r = position r in the list) and one stream per rank.
+// One stream per rank (rank r = position r in the device list) and, for the RCCL transport, one
+// communicator per rank; for the peer-copy transport one event per rank instead.
 struct GatherCtx {
   std::vector<int> devs;
+  bool rccl = true;
   std::vector<ncclComm_t> comms;
   std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> arrived;
 };
 
 namespace {
-std::map<std::vector<int>, std::unique_ptr<GatherCtx>> g_ctx;
+std::map<std::pair<std::vector<int>, bool>, std::unique_ptr<GatherCtx>> g_ctx;
 
 __global__ __launch_bounds__(256) void pack_records_kernel(const uint64_t *__restrict__ idx,
                                                            const uint32_t *__restrict__ d32, long long cnt,
@@ -121,29 +127,35 @@ std::mutex &gather_mutex() { return g_rccl_mutex; }
 
 // Caller holds gather_mutex().  The clique (ncclCommInitAll takes seconds) and its streams live
 // until the process ends.
-int gather_ctx_get(const std::vector<int> &devs, GatherCtx **out) {
-  SPV_TRY(rccl_load());
-  auto it = g_ctx.find(devs);
+int gather_ctx_get(const std::vector<int> &devs, bool use_rccl, GatherCtx **out) {
+  const auto key = std::make_pair(devs, use_rccl);
+  auto it = g_ctx.find(key);
   if (it != g_ctx.end()) {
     *out = it->second.get();
     return SPV_OK;
   }
-  for (size_t a = 0; a < devs.size(); ++a)
-    for (size_t b = a + 1; b < devs.size(); ++b)
-      if (devs[a] == devs[b])
-        return set_error(SPV_ERR_INVALID, "device %d is listed twice: an RCCL clique needs distinct devices "
-                                          "(use SPECTAVI_GATHER=direct for such a list)", devs[a]);
   std::unique_ptr<GatherCtx> ctx(new GatherCtx);
   ctx->devs = devs;
-  ctx->comms.assign(devs.size(), nullptr);
-  SPV_NCCL_CHECK(g_rccl.CommInitAll(ctx->comms.data(), (int)devs.size(), devs.data()));
+  ctx->rccl = use_rccl;
+  if (use_rccl) {
+    SPV_TRY(rccl_load());
+    for (size_t a = 0; a < devs.size(); ++a)
+      for (size_t b = a + 1; b < devs.size(); ++b)
+        if (devs[a] == devs[b])
+          return set_error(SPV_ERR_INVALID, "device %d is listed twice: an RCCL clique needs distinct devices "
+                                            "(use SPECTAVI_GATHER=copy or direct for such a list)", devs[a]);
+    ctx->comms.assign(devs.size(), nullptr);
+    SPV_NCCL_CHECK(g_rccl.CommInitAll(ctx->comms.data(), (int)devs.size(), devs.data()));
+  }
   ctx->streams.assign(devs.size(), nullptr);
+  ctx->arrived.assign(devs.size(), nullptr);
   for (size_t r = 0; r < devs.size(); ++r) {
     SPV_HIP_CHECK(hipSetDevice(devs[r]));
     SPV_HIP_CHECK(hipStreamCreateWithFlags(&ctx->streams[r], hipStreamNonBlocking));
+    if (!use_rccl) SPV_HIP_CHECK(hipEventCreateWithFlags(&ctx->arrived[r], hipEventDisableTiming));
   }
   *out = ctx.get();
-  g_ctx[devs] = std::move(ctx);
+  g_ctx[key] = std::move(ctx);
   return SPV_OK;
 }
 
@@ -167,6 +179,19 @@ int gather_bytes_run(GatherCtx *ctx, const std::vector<const void *> &d_send, vo
   if ((int)d_send.size() != G) return set_error(SPV_ERR_INTERNAL, "gather: %zu buffers for %d ranks", d_send.size(), G);
   SPV_HIP_CHECK(hipSetDevice(ctx->devs[0]));
   ProfScope prof("gather", ctx->streams[0]);
+  if (!ctx->rccl) {
+    // peer-copy transport: rank r's stream copies its block into slot r of the root's buffer (the
+    // same layout ncclGather produces); the root's stream then waits for every rank's copy
+    for (int r = 0; r < G; ++r) {
+      SPV_HIP_CHECK(hipSetDevice(ctx->devs[r]));
+      SPV_HIP_CHECK(hipMemcpyPeerAsync(static_cast<char *>(d_recv_root) + (size_t)r * bytes_per_rank, ctx->devs[0],
+                                       d_send[r], ctx->devs[r], bytes_per_rank, ctx->streams[r]));
+      SPV_HIP_CHECK(hipEventRecord(ctx->arrived[r], ctx->streams[r]));
+    }
+    SPV_HIP_CHECK(hipSetDevice(ctx->devs[0]));
+    for (int r = 1; r < G; ++r) SPV_HIP_CHECK(hipStreamWaitEvent(ctx->streams[0], ctx->arrived[r], 0));
+    return SPV_OK;
+  }
   SPV_NCCL_CHECK(g_rccl.GroupStart());
   for (int r = 0; r < G; ++r) {
     const ncclResult_t res = g_rccl.Gather(d_send[r], r == 0 ? d_recv_root : nullptr, bytes_per_rank, ncclInt8, 0,

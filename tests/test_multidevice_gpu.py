@@ -244,3 +244,49 @@ def test_host_entry_points_restore_the_callers_device():
     assert torch.cuda.current_device() == before
     t = torch.ones(4, device="cuda") * 2            # torch still works on its device afterwards
     assert float(t.sum()) == 8.0
+
+
+@pytest.fixture
+def three_ranks_copy_transport():
+    """The gathered multi-rank layout on a one-GPU box: device 0 listed three times, records moved into
+    the root's [rank][max_cnt] buffer by the peer-copy transport (RCCL refuses a duplicated device).
+    Everything but the collective itself is the code that runs over RCCL on eight GPUs: ragged shard
+    bounds, padding to the largest shard, rank order, the widening kernel, the ncand and DLT segments."""
+    import spectavi_amd
+    spectavi_amd.set_devices([0, 0, 0])
+    spectavi_amd.set_gather_mode("copy")
+    yield
+    spectavi_amd.set_gather_mode("auto")
+    spectavi_amd.set_devices([0])
+
+
+def test_gathered_layout_three_ranks(oracle, three_ranks_copy_transport):
+    from spectavi_amd import device, feature, mvg
+    device.profile_reset()
+    device.profile_enable(True)
+    rng = np.random.default_rng(303)
+    x = rng.integers(0, 256, (3000, 128), dtype=np.uint8)
+    for nq in (1001, 1000, 2, 4):                           # ragged, even, fewer rows than ranks, one extra
+        y = rng.integers(0, 256, (nq, 128), dtype=np.uint8)
+        idx, dist = feature.nn_bruteforcel1k2(x, y)
+        oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+        assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), nq
+    idx1, dist1 = feature.nn_bruteforcel1k2(x[:1], y)      # sentinels through three ranks' records
+    oidx1, odist1 = oracle.nn_bruteforcel1k2(x[:1], y)
+    assert np.array_equal(idx1, oidx1) and np.array_equal(dist1, odist1)
+
+    y = rng.integers(0, 256, (1001, 128), dtype=np.uint8)
+    xf, yf = x.astype(np.float32) - 128, y.astype(np.float32) - 128
+    d = rng.standard_normal((2, 128, 8)).astype(np.float32)
+    cidx, cdist, ncand = feature.nn_cascading_hash_with_dict(xf, yf, d, g=2, return_ncand=True)
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(xf, yf, 8, 2, 2, d)
+    assert np.array_equal(cidx, oidx) and np.array_equal(cdist, odist) and np.array_equal(ncand, oncand)
+
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((10007, 4))
+    X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert np.array_equal(X, oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))
+    e = mvg.dlt_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T)
+    assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T))
+    device.profile_enable(False)
+    assert device.profile_read("gather")[0] == 5 + 2 + 2    # five L1 calls, cascade records + ncand, two DLT calls
