@@ -36,8 +36,9 @@ def dlt(npt=1_000_000):
     t0 = time.perf_counter()
     o.dlt_triangulate(P0, P1, x, xp)
     dt = time.perf_counter() - t0
-    return {"path": "dlt_triangulate (serial loop, as reference src/Spectavi.cpp:48-51)", "points": npt,
-            "threads": 1, "seconds": dt, "points_per_s": npt / dt}
+    return {"path": "dlt_triangulate (serial loop, as reference src/Spectavi.cpp:48-51; per point the "
+                    "two-sided JacobiSVD of oracle_jacobisvd.cpp, the reference's own algorithm restated)",
+            "points": npt, "threads": 1, "seconds": dt, "points_per_s": npt / dt}
 
 
 if __name__ == "__main__":
@@ -45,7 +46,7 @@ if __name__ == "__main__":
     cpu = [l for l in open("/proc/cpuinfo") if l.startswith("model name")]
     print(json.dumps({"cpu": cpu[0].split(":", 1)[1].strip() if cpu else "?", "logical_cpus": os.cpu_count(),
                       "omp_max_threads": allc}), flush=True)
-    for xrows in (1000, 262144):
+    for xrows in (1000, 262144, 1_000_000):
         for th in sorted({1, 8, allc}):
             print(json.dumps(l1k2(xrows, 128, th)), flush=True)
     print(json.dumps(dlt()), flush=True)
