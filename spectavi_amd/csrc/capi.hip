@@ -567,6 +567,8 @@ class D2HPipeline {
       }
       const size_t len = std::min(piece_, c1 - off);
       const int slot = k & 1;
+      if (prev_slot == slot) drain();  // (a skipped chunk in between) never overwrite an undrained buffer
+      if (!ok) break;
       hipError_t e = ev ? hipStreamWaitEvent(st, ev, 0) : hipSuccess;
       if (e == hipSuccess) e = hipMemcpyAsync(pin[slot], src_ + off, len, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipEventRecord(done[slot], st);
