@@ -289,14 +289,24 @@ __global__ __launch_bounds__(kThreads, 2) void l1k2_wide_kernel(const uint4 *__r
   extern __shared__ uint4 wtile[];  // [kWideRows][D4 / 4]
   const int V4 = D4 / 4;
   const int t = threadIdx.x;
-  const int s = blockIdx.y;
+  // XCD-aware block -> (query block, slice): every database tile makes a workgroup re-read its
+  // queries' chunks, 256 Q rows against 16 database rows, so the query block must stay in the L2 of
+  // the XCD that runs it.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8): all slices
+  // of query block qb are given ids = qb (mod 8), so they run on one XCD, one after the other, and an
+  // XCD works on ~3 query blocks (<= 1 MB at dim 2048) at a time.  (Speed only: nothing depends on the
+  // placement.)  With the plain (query block, slice) grid 256k x 256k x 512 was bound by those re-reads
+  // at 0.61 of the SAD peak.
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int s = rest % S;
+  const int qb = (rest / S) * 8 + xcd;
+  if ((long long)qb * (kThreads * Q) >= N) return;  // padding of the query blocks to a multiple of 8
   const int row_begin = s * slice_rows;
   const int row_end = min(M, row_begin + slice_rows);
   int qi[Q];
   const uint4 *yq[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    qi[q] = blockIdx.x * (kThreads * Q) + q * kThreads + t;
+    qi[q] = qb * (kThreads * Q) + q * kThreads + t;
     yq[q] = y + (size_t)min(qi[q], N - 1) * V4;
   }
   uint32_t d1[Q], d2[Q], i1[Q], i2[Q];
@@ -569,7 +579,7 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
       if (p.dim_pad <= 256 || p.dim_pad > kMaxGenericDim || p.dim_pad % 128)
         return set_error(SPV_ERR_INVALID, "internal: bad dim_pad %d", p.dim_pad);
       const size_t lds = (size_t)kWideRows * p.dim_pad;
-      const dim3 grid(p.qblocks, p.slices);
+      const dim3 grid((unsigned)((p.qblocks + 7) / 8 * 8 * p.slices));  // decoded XCD-aware in the kernel
       if (p.q >= 2)
         hipLaunchKernelGGL((l1k2_wide_kernel<2>), grid, dim3(kThreads), lds, stream,
                            reinterpret_cast<const uint4 *>(kx), reinterpret_cast<const uint4 *>(ky), xrows, yrows,
