@@ -318,6 +318,15 @@ int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int n
                                     long long npt, const double *d_x, const double *d_xp,
                                     double max_error, int32_t *d_counts, uint8_t *d_mask,
                                     void *stream);
+/* The same with a workspace (spv_dlt_score_workspace_bytes): the solves that do not converge on the
+ * fast path are collected in a work list and finished by a second kernel in full waves instead of
+ * in place -- same results, about three times the throughput on RANSAC-like hypotheses.  A NULL or
+ * short workspace falls back to the one-pass form. */
+size_t spv_dlt_score_workspace_bytes(int nhyp, long long npt);
+int spv_dlt_score_hypotheses_device_ws(const double *P0, const double *d_P1s, int nhyp, long long npt,
+                                       const double *d_x, const double *d_xp, double max_error,
+                                       int32_t *d_counts, uint8_t *d_mask, void *d_ws, size_t ws_bytes,
+                                       void *stream);
 
 #ifdef __cplusplus
 }

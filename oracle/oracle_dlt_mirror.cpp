@@ -148,9 +148,9 @@ inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4])
   return true;
 }
 
-// fast = true: method 2 with method 1 as fallback (dlt_triangulate / dlt_reprojection_error);
-// fast = false: method 1 only (RANSAC scoring, where most hypotheses are inconsistent and
-// method 2 would rarely converge).
+// fast = true: method 2 with method 1 as fallback (dlt_triangulate / dlt_reprojection_error and,
+// since round 2, RANSAC scoring: the kernel defers its slow lanes to a second pass, the result per
+// (hypothesis, point) pair is this function's); fast = false: method 1 only.
 inline void dlt_solve(const double *P0, const double *P1, const double *x, const double *xp,
                       Solve &out, bool fast = true) {
   const double u = x[0] / x[2], v = x[1] / x[2];
@@ -260,7 +260,7 @@ void oracle_dlt_mirror_score_hypotheses(const double *P0, const double *P1s, int
     int cnt = 0;
     for (int i = 0; i < npt; ++i) {
       Solve s;
-      dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s, /*fast=*/false);
+      dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s, /*fast=*/true);
       double r0[3], r1[3];
       reproject(P0, s.X, r0);
       reproject(P1, s.X, r1);

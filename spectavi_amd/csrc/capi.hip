@@ -832,12 +832,14 @@ int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const
   if (!P0 || !P1s || !counts || (npt > 0 && (!x || !xp))) return set_error(SPV_ERR_INVALID, "null pointer");
   SPV_TRY(ensure_device());
   const size_t ib = (size_t)npt * 3 * sizeof(double);
-  DevBuf dx, dxp, dp, dc, dm;
+  DevBuf dx, dxp, dp, dc, dm, ws;
+  const size_t wsb = dlt_score_workspace_bytes(nhyp, npt);
   SPV_TRY(dx.alloc(ib));
   SPV_TRY(dxp.alloc(ib));
   SPV_TRY(dp.alloc((size_t)nhyp * 12 * sizeof(double)));
   SPV_TRY(dc.alloc((size_t)nhyp * sizeof(int32_t)));
   if (mask) SPV_TRY(dm.alloc((size_t)nhyp * npt));
+  SPV_TRY(ws.alloc(wsb));
   hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   if (ib) {
     SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
@@ -845,7 +847,7 @@ int host_dlt_score(const double *P0, const double *P1s, int nhyp, int npt, const
   }
   SPV_HIP_CHECK(hipMemcpyAsync(dp.p, P1s, (size_t)nhyp * 12 * sizeof(double), hipMemcpyHostToDevice, st));
   SPV_TRY(dlt_score_run(P0, dp.as<double>(), nhyp, npt, dx.as<double>(), dxp.as<double>(), max_error,
-                        dc.as<int>(), mask ? dm.as<unsigned char>() : nullptr, st));
+                        dc.as<int>(), mask ? dm.as<unsigned char>() : nullptr, ws.p, wsb, st));
   SPV_HIP_CHECK(hipMemcpyAsync(counts, dc.p, (size_t)nhyp * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   if (mask && npt > 0)
     SPV_HIP_CHECK(hipMemcpyAsync(mask, dm.p, (size_t)nhyp * npt, hipMemcpyDeviceToHost, st));
@@ -1494,8 +1496,17 @@ int spv_dlt_score_hypotheses_device(const double *P0, const double *d_P1s, int n
                                     double max_error, int32_t *d_counts, uint8_t *d_mask,
                                     void *stream) {
   clear_error();
-  return guard([&] { return dlt_score_run(P0, d_P1s, nhyp, npt, d_x, d_xp, max_error, d_counts, d_mask,
+  return guard([&] { return dlt_score_run(P0, d_P1s, nhyp, npt, d_x, d_xp, max_error, d_counts, d_mask, nullptr, 0,
                        static_cast<hipStream_t>(stream)); });
+}
+size_t spv_dlt_score_workspace_bytes(int nhyp, long long npt) { return dlt_score_workspace_bytes(nhyp, npt); }
+int spv_dlt_score_hypotheses_device_ws(const double *P0, const double *d_P1s, int nhyp, long long npt,
+                                       const double *d_x, const double *d_xp, double max_error,
+                                       int32_t *d_counts, uint8_t *d_mask, void *d_ws, size_t ws_bytes,
+                                       void *stream) {
+  clear_error();
+  return guard([&] { return dlt_score_run(P0, d_P1s, nhyp, npt, d_x, d_xp, max_error, d_counts, d_mask, d_ws,
+                       ws_bytes, static_cast<hipStream_t>(stream)); });
 }
 int spv_dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                                const double *xp, double *dst) {

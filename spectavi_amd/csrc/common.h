@@ -106,9 +106,12 @@ int gather_bytes_run(GatherCtx *ctx, const std::vector<const void *> &d_send, vo
 int gather_widen_run(const void *d_recv, long long total, int G, long long max_cnt, uint64_t *d_idx, void *d_d32,
                      hipStream_t stream);
 
+size_t dlt_score_workspace_bytes(int nhyp, long long npt);
+// d_ws (may be NULL / short: the scorer then runs in one pass, same results) holds the work list of
+// the solves that are deferred to the second pass
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
-                  const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,
-                  hipStream_t stream);
+                  const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask, void *d_ws,
+                  size_t ws_bytes, hipStream_t stream);
 
 
 // ---- RANSAC candidate processing (dlt.hip): gate, E, four cameras, scoring, best camera ----

@@ -193,16 +193,14 @@ __device__ __forceinline__ bool null_gs_inverse_iteration(const double (&A0)[4][
 // FAST: method 2 with method 1 as fallback (triangulate / reprojection error: consistent
 // correspondences, sigma4 << sigma3); !FAST: method 1 only (RANSAC scoring, where most
 // hypotheses are inconsistent and method 2 would rarely converge).
-template <bool FAST>
-__device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double x1, double x2,
-                                          double y0, double y1, double y2, double (&X)[4],
-                                          double &u, double &v, double &up, double &vp) {
-  // hnormalize (reference src/DltTriangulator.h:38-45)
+// A = [u P0[2]-P0[0]; v P0[2]-P0[1]; u' P1[2]-P1[0]; v' P1[2]-P1[1]] (reference src/DltTriangulator.h:38-54)
+__device__ __forceinline__ void dlt_matrix(const Cameras &cam, double x0, double x1, double x2, double y0,
+                                           double y1, double y2, double (&A)[4][4], double &u, double &v,
+                                           double &up, double &vp) {
   u = x0 / x2;
   v = x1 / x2;
   up = y0 / y2;
   vp = y1 / y2;
-  double A[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     A[0][c] = __builtin_fma(u, cam.p0[8 + c], -cam.p0[0 + c]);
@@ -210,11 +208,10 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
     A[2][c] = __builtin_fma(up, cam.p1[8 + c], -cam.p1[0 + c]);
     A[3][c] = __builtin_fma(vp, cam.p1[8 + c], -cam.p1[4 + c]);
   }
-  double xv[4];
-  bool done = false;
-  if (FAST) done = null_gs_inverse_iteration(A, xv);
-  if (!done) null_jacobi(A, xv);
-  // renormalise (V is orthogonal up to rounding) and canonicalise the sign
+}
+
+// unit 2-norm (V is orthogonal up to rounding) and the canonical sign
+__device__ __forceinline__ void dlt_finish(const double (&xv)[4], double (&X)[4]) {
   double nrm = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) nrm = __builtin_fma(xv[i], xv[i], nrm);
@@ -231,6 +228,21 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
   const double scale = 1.0 / (neg ? -nrm : nrm);
 #pragma unroll
   for (int i = 0; i < 4; ++i) X[i] = xv[i] * scale;
+}
+
+// FAST: method 2 with method 1 as fallback (consistent correspondences converge in 3-4 steps;
+// whatever does not within 8 takes the Jacobi); !FAST: method 1 only.
+template <bool FAST>
+__device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double x1, double x2,
+                                          double y0, double y1, double y2, double (&X)[4],
+                                          double &u, double &v, double &up, double &vp) {
+  double A[4][4];
+  dlt_matrix(cam, x0, x1, x2, y0, y1, y2, A, u, v, up, vp);
+  double xv[4];
+  bool done = false;
+  if (FAST) done = null_gs_inverse_iteration(A, xv);
+  if (!done) null_jacobi(A, xv);
+  dlt_finish(xv, X);
 }
 
 // Persistent, barrier-free: every lane walks the points p, p + stride, ... and loads the six
@@ -306,10 +318,56 @@ __device__ __forceinline__ double det3_left(const double *P) {
          P[2] * (P[4] * P[9] - P[5] * P[8]);
 }
 
+// reprojection_error() <= max_error && is_infront_both_cameras() (src/DltTriangulator.h:67-86)
+__device__ __forceinline__ bool score_inlier(const Cameras &cam, const double (&X)[4], double u, double v,
+                                             double up, double vp, double max_error) {
+  double r0[3], r1[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
+      b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
+    }
+    r0[r] = a;
+    r1[r] = b;
+  }
+  const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
+  const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
+  const double err = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
+  const double s0 = det3_left(cam.p0) < 0 ? -1.0 : 1.0, s1 = det3_left(cam.p1) < 0 ? -1.0 : 1.0;
+  const double n0 = cam.p0[2] * cam.p0[2] + cam.p0[6] * cam.p0[6] + cam.p0[10] * cam.p0[10];
+  const double n1 = cam.p1[2] * cam.p1[2] + cam.p1[6] * cam.p1[6] + cam.p1[10] * cam.p1[10];
+  const double dc0 = s0 / n0 * r0[2] / X[3];
+  const double dc1 = s1 / n1 * r1[2] / X[3];
+  return (err <= max_error) && (dc0 > 0) && (dc1 > 0);
+}
+
+// Every (correspondence, hypothesis) pair is solved by method 2 (8 steps) with method 1 as its
+// fallback, exactly as dlt_solve<true> does it for one point.  Most hypotheses of a RANSAC run are
+// wrong for most correspondences, and about one solve in five does not converge within the 8 steps
+// (sigma4 / sigma3 has a median of 0.02 but a long tail); a wave that ran the ~3100-instruction Jacobi
+// for its slow lanes in place would pay for it with all 64.  With a work list (TWO_PASS) the slow
+// lanes are appended to it instead -- one atomicAdd per wave, (hypothesis, point) packed in 8 bytes --
+// and dlt_score_fallback_kernel solves them afterwards in full waves.  Lanes that find the list full,
+// and the form without a work list, run the fallback in place: the results do not depend on the path.
+// The list is cut into kListShards segments with a counter each (64 bytes apart): every wave with
+// slow lanes does one atomicAdd, and 70 000 of them on ONE address serialise at ~12 ns each (measured:
+// the first version of this kernel spent 0.83 of its 0.9 ms there).
+constexpr unsigned int kListShards = 1024;
+constexpr unsigned int kCountStride = 16;  // uints between two counters
+struct WorkList {
+  unsigned int *count;          // [kListShards * kCountStride]; may exceed `segment`: the excess ran in place
+  unsigned long long *entries;  // [kListShards][segment], (hypothesis << 40) | point
+  unsigned int segment;         // entries per shard; 0 = no list
+};
+
+template <bool TWO_PASS>
 __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
     Cameras cam0, const double *__restrict__ p1s, long long npt, const double *__restrict__ x,
     const double *__restrict__ xp, double max_error, int *__restrict__ counts,
-    unsigned char *__restrict__ mask) {
+    unsigned char *__restrict__ mask, WorkList wl) {
   __shared__ double sx[kDltThreads * 3];
   __shared__ double sxp[kDltThreads * 3];
   const int h = blockIdx.y;
@@ -331,38 +389,75 @@ __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
   }
   __syncthreads();
   const int t = threadIdx.x;
-  bool inlier = false;
-  if (t < nblk) {
-    double X[4], u, v, up, vp;
-    dlt_solve<false>(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1],
-                     sxp[3 * t + 2], X, u, v, up, vp);
-    double r0[3], r1[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
-        b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
+  const bool live = t < nblk;
+  double A[4][4], xv[4], u = 0, v = 0, up = 0, vp = 0;
+  bool solved = true;  // dead lanes have nothing to solve
+  if (live) {
+    dlt_matrix(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1], sxp[3 * t + 2], A, u, v,
+               up, vp);
+    solved = null_gs_inverse_iteration(A, xv);
+  }
+  bool deferred = false;
+  if (TWO_PASS) {
+    // slow lanes of the wave -> work list
+    const unsigned long long slow = __ballot(!solved);
+    if (slow) {
+      const int lane = threadIdx.x & 63;
+      const unsigned int shard = (blockIdx.y * gridDim.x + blockIdx.x) * (kDltThreads / 64) + (threadIdx.x >> 6);
+      const unsigned int sh = shard % kListShards;
+      unsigned int first = 0;
+      if (lane == 0) first = atomicAdd(wl.count + sh * kCountStride, (unsigned int)__popcll(slow));
+      first = __shfl(first, 0, 64);
+      if (!solved) {
+        const unsigned int slot = first + (unsigned int)__popcll(slow & ((1ull << lane) - 1ull));
+        if (slot < wl.segment) {
+          wl.entries[(size_t)sh * wl.segment + slot] = ((unsigned long long)h << 40) | (unsigned long long)(base + t);
+          deferred = true;
+        }
       }
-      r0[r] = a;
-      r1[r] = b;
     }
-    const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
-    const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
-    const double err = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
-    const double s0 = det3_left(cam.p0) < 0 ? -1.0 : 1.0, s1 = det3_left(cam.p1) < 0 ? -1.0 : 1.0;
-    const double n0 = cam.p0[2] * cam.p0[2] + cam.p0[6] * cam.p0[6] + cam.p0[10] * cam.p0[10];
-    const double n1 = cam.p1[2] * cam.p1[2] + cam.p1[6] * cam.p1[6] + cam.p1[10] * cam.p1[10];
-    const double dc0 = s0 / n0 * r0[2] / X[3];
-    const double dc1 = s1 / n1 * r1[2] / X[3];
-    inlier = (err <= max_error) && (dc0 > 0) && (dc1 > 0);
+  }
+  if (!solved && !deferred) null_jacobi(A, xv);  // in place: no work list, or it is full
+  bool inlier = false;
+  if (live && !deferred) {
+    double X[4];
+    dlt_finish(xv, X);
+    inlier = score_inlier(cam, X, u, v, up, vp, max_error);
     if (mask) mask[(size_t)h * npt + base + t] = inlier ? 1 : 0;
   }
   const unsigned long long bal = __ballot(inlier);
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[h], __popcll(bal));
 }
 
+// Second pass: one lane per work-list entry, method 1.
+__global__ __launch_bounds__(kDltThreads) void dlt_score_fallback_kernel(
+    Cameras cam0, const double *__restrict__ p1s, long long npt, const double *__restrict__ x,
+    const double *__restrict__ xp, double max_error, int *__restrict__ counts,
+    unsigned char *__restrict__ mask, WorkList wl) {
+  const unsigned int total = kListShards * wl.segment;
+  for (unsigned int i = blockIdx.x * kDltThreads + threadIdx.x; i < total; i += gridDim.x * kDltThreads) {
+    // slot-major over the shards: consecutive lanes take the same slot of consecutive shards, so the
+    // filled part of the list (the first slots of every shard) is covered by full waves
+    const unsigned int sh = i % kListShards, slot = i / kListShards;
+    if (slot >= min(wl.count[sh * kCountStride], wl.segment)) continue;
+    const unsigned long long e = wl.entries[(size_t)sh * wl.segment + slot];
+    const int h = (int)(e >> 40);
+    const long long p = (long long)(e & ((1ull << 40) - 1ull));
+    Cameras cam;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      cam.p0[k] = cam0.p0[k];
+      cam.p1[k] = p1s[(size_t)h * 12 + k];
+    }
+    double A[4][4], xv[4], X[4], u, v, up, vp;
+    dlt_matrix(cam, x[3 * p], x[3 * p + 1], x[3 * p + 2], xp[3 * p], xp[3 * p + 1], xp[3 * p + 2], A, u, v, up, vp);
+    null_jacobi(A, xv);
+    dlt_finish(xv, X);
+    const bool inlier = score_inlier(cam, X, u, v, up, vp, max_error);
+    if (mask) mask[(size_t)h * npt + p] = inlier ? 1 : 0;
+    if (inlier) atomicAdd(&counts[h], 1);
+  }
+}
 
 // ---------------------------------------------------------------------------------
 // RANSAC candidate processing (the rest of it): what the reference's
@@ -642,6 +737,7 @@ size_t ransac_workspace_bytes(int nF, long long npt, bool want_mask) {
   b += round_up((size_t)nF * 4 * sizeof(int), 256);                 // inlier counts
   b += round_up((size_t)nF * sizeof(int), 256);                     // gate flags
   if (want_mask) b += round_up((size_t)nF * 4 * (size_t)npt, 256);  // per-camera inlier masks
+  b += dlt_score_workspace_bytes(4 * nF, npt);                      // the scorer's work list
   return b;
 }
 
@@ -666,6 +762,8 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
   int *gated = reinterpret_cast<int *>(ws);
   ws += round_up((size_t)nF * sizeof(int), 256);
   unsigned char *mask4 = d_mask ? ws : nullptr;
+  if (d_mask) ws += round_up((size_t)nF * 4 * (size_t)npt, 256);
+  const size_t score_ws = dlt_score_workspace_bytes(4 * nF, npt);
   const int fblocks = (nF + kDltThreads - 1) / kDltThreads;
   {
     ProfScope prof("ransac_cameras", stream);
@@ -674,7 +772,7 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
     SPV_HIP_CHECK(hipGetLastError());
   }
   const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // Camera(): Identity(3,4), src/Camera.h:27
-  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, stream));
+  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, ws, score_ws, stream));
   hipLaunchKernelGGL(select_camera_kernel, dim3(fblocks), dim3(kDltThreads), 0, stream, counts, gated, cams, nF, npt,
                      required_percent, find_best, d_success, d_inlier_count, d_best_cam, d_best_P, d_counts4);
   SPV_HIP_CHECK(hipGetLastError());
@@ -687,9 +785,23 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
   return SPV_OK;
 }
 
+// Work list of the two-pass scorer: kListShards counters (64 bytes apart) + as many segments of
+// deferred (hypothesis, point) pairs, up to 2^22 in all.
+static unsigned int score_segment(int nhyp, long long npt) {
+  const unsigned long long pairs = (unsigned long long)nhyp * (unsigned long long)npt;
+  const unsigned long long cap = std::min<unsigned long long>(pairs, 1ull << 22);
+  return (unsigned int)std::max<unsigned long long>((cap + kListShards - 1) / kListShards, 64);
+}
+constexpr size_t kScoreCountBytes = (size_t)kListShards * kCountStride * sizeof(unsigned int);
+
+size_t dlt_score_workspace_bytes(int nhyp, long long npt) {
+  if (nhyp <= 0 || npt <= 0) return 0;
+  return kScoreCountBytes + (size_t)kListShards * score_segment(nhyp, npt) * sizeof(unsigned long long);
+}
+
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
-                  const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask,
-                  hipStream_t stream) {
+                  const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask, void *d_ws,
+                  size_t ws_bytes, hipStream_t stream) {
   if (npt < 0 || nhyp < 0) return set_error(SPV_ERR_INVALID, "negative count");
   if (!P0) return set_error(SPV_ERR_INVALID, "null camera pointer");
   if (nhyp == 0) return SPV_OK;
@@ -698,13 +810,36 @@ int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt
   if (npt == 0) return SPV_OK;
   if (!d_x || !d_xp) return set_error(SPV_ERR_INVALID, "null device pointer");
   if (nhyp > 65535) return set_error(SPV_ERR_INVALID, "more than 65535 hypotheses per call");
+  if (npt >= (1ll << 40)) return set_error(SPV_ERR_INVALID, "too many points");
   Cameras cam0;
   for (int i = 0; i < 12; ++i) cam0.p0[i] = cam0.p1[i] = P0[i];
   const long long blocks = (npt + kDltThreads - 1) / kDltThreads;
   if (blocks > 0x7FFFFFFFLL) return set_error(SPV_ERR_INVALID, "too many points");
   ProfScope prof("dlt_score", stream);
-  hipLaunchKernelGGL(dlt_score_kernel, dim3((unsigned)blocks, (unsigned)nhyp), dim3(kDltThreads), 0,
-                     stream, cam0, d_p1s, npt, d_x, d_xp, max_error, d_counts, d_mask);
+  const dim3 grid((unsigned)blocks, (unsigned)nhyp);
+  // a workspace too small for the work list is not an error: the scorer then runs in one pass
+  WorkList wl{nullptr, nullptr, 0};
+  if (d_ws && ws_bytes > kScoreCountBytes && (reinterpret_cast<uintptr_t>(d_ws) & 7) == 0) {
+    wl.count = static_cast<unsigned int *>(d_ws);
+    wl.entries = reinterpret_cast<unsigned long long *>(static_cast<char *>(d_ws) + kScoreCountBytes);
+    wl.segment = (unsigned int)std::min<size_t>((ws_bytes - kScoreCountBytes) / sizeof(unsigned long long) / kListShards,
+                                                score_segment(nhyp, npt));
+  }
+  if (wl.segment == 0) {
+    hipLaunchKernelGGL(dlt_score_kernel<false>, grid, dim3(kDltThreads), 0, stream, cam0, d_p1s, npt, d_x, d_xp,
+                       max_error, d_counts, d_mask, wl);
+    SPV_HIP_CHECK(hipGetLastError());
+    return SPV_OK;
+  }
+  SPV_HIP_CHECK(hipMemsetAsync(wl.count, 0, kScoreCountBytes, stream));
+  hipLaunchKernelGGL(dlt_score_kernel<true>, grid, dim3(kDltThreads), 0, stream, cam0, d_p1s, npt, d_x, d_xp,
+                     max_error, d_counts, d_mask, wl);
+  SPV_HIP_CHECK(hipGetLastError());
+  // the list's length is only known on the device: a grid that covers a full list, strided
+  const unsigned fb = (unsigned)std::min<unsigned long long>(((unsigned long long)kListShards * wl.segment + kDltThreads - 1) / kDltThreads,
+                                                             (unsigned long long)device_cu_count() * 16);
+  hipLaunchKernelGGL(dlt_score_fallback_kernel, dim3(std::max(fb, 1u)), dim3(kDltThreads), 0, stream, cam0, d_p1s, npt,
+                     d_x, d_xp, max_error, d_counts, d_mask, wl);
   SPV_HIP_CHECK(hipGetLastError());
   return SPV_OK;
 }

@@ -155,6 +155,11 @@ clib.spv_ratio_test_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_double
 clib.spv_dlt_score_hypotheses_device.restype = ct.c_int
 clib.spv_dlt_score_hypotheses_device.argtypes = [_f64p, _vp, ct.c_int, ct.c_longlong, _vp, _vp, ct.c_double,
                                                  _vp, _vp, _vp]
+clib.spv_dlt_score_workspace_bytes.restype = ct.c_size_t
+clib.spv_dlt_score_workspace_bytes.argtypes = [ct.c_int, ct.c_longlong]
+clib.spv_dlt_score_hypotheses_device_ws.restype = ct.c_int
+clib.spv_dlt_score_hypotheses_device_ws.argtypes = [_f64p, _vp, ct.c_int, ct.c_longlong, _vp, _vp, ct.c_double,
+                                                    _vp, _vp, _vp, ct.c_size_t, _vp]
 
 
 def ratio_test(idx, dist, min_ratio, workspace=None):
@@ -178,7 +183,7 @@ def ratio_test(idx, dist, min_ratio, workspace=None):
     return matches, count
 
 
-def dlt_score_hypotheses(P0, P1s, x, xp, max_error, want_mask=False):
+def dlt_score_hypotheses(P0, P1s, x, xp, max_error, want_mask=False, workspace=None):
     """RANSAC scoring on device: P0 host [3,4]; P1s CUDA float64 [H,3,4]; x,xp CUDA [npt,3].
     Returns counts int32 [H] (and mask uint8 [H,npt])."""
     _need(P1s, torch.float64, "P1s")
@@ -189,9 +194,11 @@ def dlt_score_hypotheses(P0, P1s, x, xp, max_error, want_mask=False):
     counts = torch.empty((nh,), dtype=torch.int32, device=x.device)
     mask = torch.empty((nh, npt), dtype=torch.uint8, device=x.device) if want_mask else None
     with _on_device_of(P1s, x, xp) as stream:
-        check(clib.spv_dlt_score_hypotheses_device(P0, P1s.data_ptr(), nh, npt, x.data_ptr(), xp.data_ptr(),
-                                                   float(max_error), counts.data_ptr(),
-                                                   mask.data_ptr() if want_mask else None, stream))
+        ws = (workspace or _default_ws).get(clib.spv_dlt_score_workspace_bytes(nh, npt), x.device)
+        check(clib.spv_dlt_score_hypotheses_device_ws(P0, P1s.data_ptr(), nh, npt, x.data_ptr(), xp.data_ptr(),
+                                                      float(max_error), counts.data_ptr(),
+                                                      mask.data_ptr() if want_mask else None, ws.data_ptr(),
+                                                      ws.numel(), stream))
     return (counts, mask) if want_mask else counts
 
 

@@ -199,3 +199,41 @@ def test_large_host_call_is_chunked_and_pipelined(oracle):
     assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp))
     sub = rng.integers(0, npt, 20000)
     dc.check_definition(X[sub], P0, P1, x[sub], xp[sub], err=e[sub], what="large host call")
+
+
+def test_two_pass_scorer_paths_agree(oracle):
+    """The RANSAC scorer defers the solves that do not converge on its fast path to a second kernel
+    (work list in the caller's workspace).  Whatever the work list holds -- everything, the first few
+    entries of an undersized one, or nothing (no workspace: all in place) -- counts and masks are the
+    same bits, and they are the host mirror's."""
+    import ctypes as ct
+    import torch
+    from spectavi_amd import device
+    from spectavi_amd._lib import clib, check
+    rng = np.random.default_rng(21)
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    cams = _essential_cameras(rng)
+    npt = 3001
+    Xw = np.hstack([rng.standard_normal((npt, 2)), rng.uniform(4, 8, (npt, 1)), np.ones((npt, 1))])
+    x, xp = Xw @ P0.T, Xw @ cams[0].T
+    xp[:, :2] += rng.normal(0, 2e-3, (npt, 2)) * xp[:, 2:3]
+    xp[::4] = rng.standard_normal((len(xp[::4]), 3))
+    P1s = np.stack(cams + [c + 0.05 * rng.standard_normal((3, 4)) for c in cams] + [rng.standard_normal((3, 4)) for _ in range(9)])
+    want_c, want_m = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, 1e-2)
+    dP, dx, dxp = torch.from_numpy(P1s).cuda(), torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda()
+    nh = P1s.shape[0]
+    full = clib.spv_dlt_score_workspace_bytes(nh, npt)
+    for ws_bytes in (full, 65536 + 8 * 1024 * 3, 65536 + 8 * 1024, 4096, 0):   # full list, 3 / 1 entries per shard, too small, none
+        counts = torch.full((nh,), -7, dtype=torch.int32, device="cuda")
+        mask = torch.full((nh, npt), 9, dtype=torch.uint8, device="cuda")
+        ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device="cuda")
+        check(clib.spv_dlt_score_hypotheses_device_ws(P0, dP.data_ptr(), nh, npt, dx.data_ptr(), dxp.data_ptr(), 1e-2,
+                                                      counts.data_ptr(), mask.data_ptr(),
+                                                      ws.data_ptr() if ws_bytes else None, ws_bytes, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(counts.cpu().numpy(), want_c), ws_bytes
+        assert np.array_equal(mask.cpu().numpy().astype(bool), want_m), ws_bytes
+    c2, m2 = device.dlt_score_hypotheses(P0, dP, dx, dxp, 1e-2, want_mask=True)
+    assert np.array_equal(c2.cpu().numpy(), want_c) and np.array_equal(m2.cpu().numpy().astype(bool), want_m)
+    # some of these solves really do take the second pass
+    assert (want_c < npt).any()
