@@ -290,3 +290,75 @@ def test_gathered_layout_three_ranks(oracle, three_ranks_copy_transport):
     assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T))
     device.profile_enable(False)
     assert device.profile_read("gather")[0] == 5 + 2 + 2    # five L1 calls, cascade records + ncand, two DLT calls
+
+
+def _hip_rank(rank, world, port, nq, out_path):
+    """One of `world` processes sharing GPU 0: HIP local compute on its query shard, the records
+    gathered over gloo (RCCL cannot span ranks that share one device)."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spectavi_amd import device
+    from spectavi_amd.sharded import nn_bruteforcel1k2_sharded, nn_cascading_hash_sharded, dlt_sharded, shard_bounds
+    rng = np.random.default_rng(123)
+    x = rng.integers(0, 256, (5000, 128), dtype=np.uint8)
+    y = rng.integers(0, 256, (nq, 128), dtype=np.uint8)
+    d = rng.standard_normal((2, 128, 9)).astype(np.float32)
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((nq, 4))
+    lo, hi = shard_bounds(nq, world, rank)
+    dev = torch.device("cuda", 0)
+
+    def l1(xt, yt):  # HIP on the device, records back on the CPU for the gloo gather
+        i, dd = device.l1k2(xt.to(dev), yt.to(dev))
+        return i.cpu(), dd.cpu()
+
+    def casc(xt, yt, dt, g):
+        i, dd = device.cascade(xt.to(dev), yt.to(dev), dt.to(dev), g=g)
+        return i.cpu(), dd.cpu()
+
+    def tri(a, b, c, e):
+        return device.dlt_triangulate(a, b, c.to(dev), e.to(dev)).cpu()
+
+    idx, dist_ = nn_bruteforcel1k2_sharded(torch.from_numpy(x), torch.from_numpy(y[lo:hi]), nq, local_fn=l1)
+    xf, yf = torch.from_numpy(x.astype(np.float32) - 128), torch.from_numpy(y[lo:hi].astype(np.float32) - 128)
+    cidx, cdist = nn_cascading_hash_sharded(xf, yf, torch.from_numpy(d), nq, g=2, local_fn=casc)
+    X = dlt_sharded(P0, P1, torch.from_numpy((Xw @ P0.T)[lo:hi].copy()), torch.from_numpy((Xw @ P1.T)[lo:hi].copy()), nq,
+                    local_fn=tri)
+    if rank == 0:
+        np.savez(out_path, idx=idx.numpy(), dist=dist_.numpy(), cidx=cidx.numpy(), cdist=cdist.numpy(), X=X.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_ranks_hip_compute_and_gather(oracle, tmp_path):
+    """Two ranks (processes) with the HIP kernels as their local compute and a real N > 1 gather of
+    the 16-byte records (gloo: both processes share the box's one GPU): the sharded wrappers of
+    spectavi_amd/sharded.py end to end, ragged shards included."""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    nq = 2001
+    out = str(tmp_path / "ranks.npz")
+    mp.spawn(_hip_rank, args=(2, port, nq, out), nprocs=2, join=True)
+    got = np.load(out)
+    rng = np.random.default_rng(123)
+    x = rng.integers(0, 256, (5000, 128), dtype=np.uint8)
+    y = rng.integers(0, 256, (nq, 128), dtype=np.uint8)
+    d = rng.standard_normal((2, 128, 9)).astype(np.float32)
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    Xw = rng.standard_normal((nq, 4))
+    oidx, odist = oracle.nn_bruteforcel1k2(x, y, nthreads=8)
+    assert np.array_equal(got["idx"].view(np.uint64), oidx) and np.array_equal(got["dist"], odist)
+    ci, cd, _, _ = oracle.nn_cascading_hash(x.astype(np.float32) - 128, y.astype(np.float32) - 128, 9, 2, 2, d)
+    assert np.array_equal(got["cidx"].view(np.uint64), ci) and np.array_equal(got["cdist"], cd)
+    assert np.array_equal(got["X"], oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))
