@@ -20,6 +20,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 /* NdArray: the in-repo definition, or -- when libspectavi.so is built with
  * `make NDARRAY_INC=/path/to/ctypes_ndarray/src` -- the reference's own <NdArray.h>
@@ -169,6 +172,33 @@ void dlt_triangulate(const double *P0, const double *P1, int npt, const double *
 void dlt_reprojection_error(const double *P0, const double *P1, int npt, const double *x,
                             const double *xp, double *dst);
 
+/* The seven-point algorithm: the up to three fundamental matrices through seven correspondences.
+ * Replaces reference src/Spectavi.cpp:14-36 (FundamentalMatrixFitter::solve,
+ * src/FundamentalMatrixFitter.h:108-246).
+ *   x, xp: double[7,2] euclidean image points; *nroot: number of solutions (0..3);
+ *   dst: caller double[3,3,3], the first *nroot matrices written (row-major), F = z F0 + (1-z) F1
+ *   unnormalised as in the reference, with xp^T F x = 0 for the seven pairs. */
+void seven_point_algorithm(const double *x, const double *xp, int *nroot, double *dst);
+
+/* RANSAC fit of the two-view geometry.  Replaces reference src/Spectavi.cpp:70-87
+ * (RansacFitter::fit_essential, src/RansacFitter.h:152-272): per try a 7-subset of the
+ * correspondences, the seven-point solutions, every solution through
+ * process_fundamental_matrix, the best model kept; stops at the first model whose inlier share
+ * exceeds required_percent_inliers.
+ *   x0, x1: double[npt,3] homogeneous (npt >= 10, as the reference's constructor demands).
+ *   *success; essential: callee-allocated double[3,3] = the winning seven-point solution (what the
+ *   reference stores, :205); camera: double[3,4]; *inlier_percent; inlier_idx: int32[n,1].
+ *   No model kept: essential and inlier_idx are 0 x 0, camera is [I | 0], as in the reference.
+ * Tries run in batches on the device and are ranked in try order, i.e. the result is the
+ * reference's for nthread = 1 given the same subsets (with OpenMP the reference's own result
+ * depends on thread timing).  The subsets come from one std::mt19937 per call, seeded from
+ * std::random_device like the reference unless SPECTAVI_RANSAC_SEED is set.  `progressbar` is
+ * accepted and ignored. */
+void ransac_fitter(const double *x0, const double *x1, int npt, double required_percent_inliers,
+                   double reprojection_error_allowed, int maximum_tries, bool find_best_even_in_failure,
+                   double singular_value_ratio_allowed, bool progressbar, bool *success, NdArray *essential,
+                   NdArray *camera, double *inlier_percent, NdArray *inlier_idx);
+
 /* ------------------------------------------------------------------------ */
 /* 2. Host-pointer variants: caller-allocated outputs, int status            */
 /* ------------------------------------------------------------------------ */
@@ -217,7 +247,8 @@ int spv_dlt_score_hypotheses(const double *P0, const double *P1s, int nhyp, int 
  * double[nF,3,4] (zeros if none), gate_ratio double[nF], E double[nF,3,3] (NaN if gated), counts4
  * int32[nF,4] (-1 if gated), inlier_mask uint8[nF,npt] = inliers of the best camera (the
  * reference's inlier_idx, :86-94, as a mask).  The two SVDs run the same two-sided Jacobi iteration
- * as Eigen's JacobiSVD (which of the four cameras comes first depends on its column signs). */
+ * as Eigen's JacobiSVD (which of the four cameras comes first depends on its column signs).
+ * A candidate with a NaN entry is rejected like a gated one (gate_ratio NaN, counts4 -1). */
 int spv_ransac_process_candidates(const double *Fs, int nF, const double *x0, const double *x1, int npt,
                                   double singular_value_ratio_allowed, double required_percent_inliers,
                                   double reprojection_error_allowed, int find_best_even_in_failure,
@@ -234,6 +265,31 @@ int spv_ransac_process_candidates_device(const double *d_Fs, int nF, long long n
                                          int32_t *d_inlier_count, int32_t *d_best_camera, double *d_best_P,
                                          double *d_gate_ratio, double *d_E, int32_t *d_counts4,
                                          uint8_t *d_inlier_mask, void *d_ws, size_t ws_bytes, void *stream);
+
+/* Batched seven-point algorithm: x, xp double[n,7,2]; nroot int32[n]; Fs double[n,3,3,3] (slots of
+ * missing roots are NaN); basis (may be NULL) double[n,2,3,3], the null-space pair (F0, F1). */
+int spv_seven_point(const double *x, const double *xp, int n, int32_t *nroot, double *Fs, double *basis);
+int spv_seven_point_device(const double *d_x, const double *d_xp, int n, double *d_Fs, int32_t *d_nroot,
+                           double *d_basis, void *stream);
+
+/* ransac_fitter with plain outputs.  seed != 0 fixes the subsets (0: SPECTAVI_RANSAC_SEED if set,
+ * else std::random_device); spv_ransac_sample(seed, npt, ntries, samples) writes the very subsets
+ * (int32[ntries,7], drawn as the reference's floyd_sample draws them, src/RansacFitter.h:120-132)
+ * that spv_ransac_fit(seed) uses, and spv_ransac_fit_samples takes them from the caller.
+ *   essential double[9], camera double[12] (untouched if no model was kept), inlier_idx int32[npt]
+ *   (first *n_inliers entries); optional (NULL to skip): *best_try / *best_root (-1 if none),
+ *   *tries_run (tries actually evaluated: batches end early at the first success). */
+int spv_ransac_sample(unsigned long long seed, int npt, int ntries, int32_t *samples);
+int spv_ransac_fit(const double *x0, const double *x1, int npt, double required_percent_inliers,
+                   double reprojection_error_allowed, int maximum_tries, int find_best_even_in_failure,
+                   double singular_value_ratio_allowed, unsigned long long seed, int32_t *success,
+                   double *essential, double *camera, double *inlier_percent, int32_t *inlier_idx,
+                   int32_t *n_inliers, int32_t *best_try, int32_t *best_root, int32_t *tries_run);
+int spv_ransac_fit_samples(const double *x0, const double *x1, int npt, double required_percent_inliers,
+                           double reprojection_error_allowed, const int32_t *samples, int ntries,
+                           int find_best_even_in_failure, double singular_value_ratio_allowed, int32_t *success,
+                           double *essential, double *camera, double *inlier_percent, int32_t *inlier_idx,
+                           int32_t *n_inliers, int32_t *best_try, int32_t *best_root, int32_t *tries_run);
 
 int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                         const double *xp, double *dst);

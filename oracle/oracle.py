@@ -84,6 +84,12 @@ def lib():
         L.oracle_process_fundamental_matrix.argtypes = [
             f64, ct.c_double, f64, f64, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
             ct.POINTER(ct.c_int32), f64, i32, ct.POINTER(ct.c_double), f64, i32]
+        L.oracle_seven_point.restype = None
+        L.oracle_seven_point.argtypes = [f64, f64, ct.POINTER(ct.c_int), f64, f64]
+        L.oracle_ransac_fit.restype = None
+        L.oracle_ransac_fit.argtypes = [f64, f64, ct.c_int, ct.c_double, ct.c_double, ct.c_int, ct.c_double, i32,
+                                        ct.c_int, ct.POINTER(ct.c_int), f64, f64, ct.POINTER(ct.c_double), i32,
+                                        ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
         L.oracle_max_threads.restype = ct.c_int
         _lib = L
     return _lib
@@ -223,6 +229,40 @@ def process_fundamental_matrix(F, x0, x1, singular_value_ratio_allowed=3e-2, req
     return {"success": bool(ok), "inlier_count": int(cnt.value) if ok else 0, "best_P": best_P if ok else None,
             "inlier_idx": idx[:cnt.value].copy() if ok else np.zeros(0, np.int32), "gate_ratio": float(ratio.value),
             "E": E, "counts4": counts4}
+
+
+def seven_point(x, xp, return_basis=False):
+    """Reference seven_point_algorithm (src/Spectavi.cpp:14-36): x, xp [7,2] euclidean.
+    Returns Fs [nroot,3,3] (and the null-space basis [2,3,3] the roots were taken in)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    xp = np.ascontiguousarray(xp, dtype=np.float64)
+    assert x.shape == (7, 2) and xp.shape == (7, 2)
+    nroot = ct.c_int(0)
+    Fs, basis = np.zeros((3, 3, 3)), np.zeros((2, 3, 3))
+    lib().oracle_seven_point(x, xp, ct.byref(nroot), Fs.reshape(-1), basis.reshape(-1))
+    return (Fs[:nroot.value].copy(), basis) if return_basis else Fs[:nroot.value].copy()
+
+
+def ransac_fit(x0, x1, samples, required_percent_inliers=0.9, reprojection_error_allowed=0.5,
+               find_best_even_in_failure=True, singular_value_ratio_allowed=3e-2):
+    """RansacFitter::fit_essential with nthread = 1 (reference src/RansacFitter.h:152-272) over the given
+    7-subsets (int32 [ntries,7]).  Returns the dict the reference front-end returns plus best_try / best_root."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    samples = np.ascontiguousarray(samples, dtype=np.int32)
+    assert x0.shape == x1.shape and x0.shape[1] == 3 and samples.ndim == 2 and samples.shape[1] == 7
+    npt = x0.shape[0]
+    ok, n, bt, br = ct.c_int(0), ct.c_int(0), ct.c_int(-1), ct.c_int(-1)
+    pct = ct.c_double(0.0)
+    F, P, idx = np.zeros(9), np.zeros(12), np.zeros(max(npt, 1), np.int32)
+    lib().oracle_ransac_fit(x0, x1, npt, float(required_percent_inliers), float(reprojection_error_allowed),
+                            int(bool(find_best_even_in_failure)), float(singular_value_ratio_allowed),
+                            samples.reshape(-1), samples.shape[0], ct.byref(ok), F, P, ct.byref(pct), idx,
+                            ct.byref(n), ct.byref(bt), ct.byref(br))
+    found = bt.value >= 0
+    return {"success": bool(ok.value), "essential": F.reshape(3, 3) if found else None,
+            "camera": P.reshape(3, 4) if found else None, "inlier_percent": float(pct.value),
+            "inlier_idx": idx[:n.value].copy(), "best_try": bt.value, "best_root": br.value}
 
 
 # ---- host mirror of the HIP kernels' operation sequence (bit-reproducibility only) -------------

@@ -907,6 +907,107 @@ int host_ransac_process(const double *Fs, int nF, const double *x0, const double
   return SPV_OK;
 }
 
+// ---- seven-point solver + RANSAC loop (ransac.hip) -----------------------------------
+int host_seven_point(const double *x, const double *xp, int n, int32_t *nroot, double *Fs, double *basis) {
+  if (n < 0) return set_error(SPV_ERR_INVALID, "negative count");
+  if (n == 0) return SPV_OK;
+  if (!x || !xp || !nroot || !Fs) return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  DevBuf dx, dxp, dF, dn, db;
+  const size_t ib = (size_t)n * 14 * sizeof(double);
+  SPV_TRY(dx.alloc(ib));
+  SPV_TRY(dxp.alloc(ib));
+  SPV_TRY(dF.alloc((size_t)n * 27 * sizeof(double)));
+  SPV_TRY(dn.alloc((size_t)n * sizeof(int32_t)));
+  if (basis) SPV_TRY(db.alloc((size_t)n * 18 * sizeof(double)));
+  hipStream_t st = hipStreamPerThread;
+  SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, ib, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, xp, ib, hipMemcpyHostToDevice, st));
+  SPV_TRY(seven_point_run(dx.as<double>(), dxp.as<double>(), n, dF.as<double>(), dn.as<int>(),
+                          basis ? db.as<double>() : nullptr, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(Fs, dF.p, (size_t)n * 27 * sizeof(double), hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(nroot, dn.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (basis) SPV_HIP_CHECK(hipMemcpyAsync(basis, db.p, (size_t)n * 18 * sizeof(double), hipMemcpyDeviceToHost, st));
+  SPV_HIP_CHECK(hipStreamSynchronize(st));
+  return SPV_OK;
+}
+
+// One 7-subset of [0, N) the way the reference draws it (floyd_sample, src/RansacFitter.h:120-132):
+// for r = N-7 .. N-1 a value v uniform on [1, r] is taken unless already present, else r.  (Row 0 is
+// therefore never drawn: the reference's range starts at 1.)  The reference seeds a fresh mt19937 from
+// std::random_device for every subset and walks an unordered_set; here one generator serves all the
+// tries of a call and the rows keep their insertion order.
+void floyd_sample(std::mt19937 &gen, int N, int *out) {
+  int n = 0;
+  for (int r = N - 7; r < N; ++r) {
+    const int v = std::uniform_int_distribution<>(1, r)(gen);
+    bool present = false;
+    for (int i = 0; i < n; ++i) present |= (out[i] == v);
+    out[n++] = present ? r : v;
+  }
+}
+
+uint32_t ransac_seed(uint64_t seed) {
+  if (seed) return (uint32_t)(seed ^ (seed >> 32));
+  if (const char *e = getenv("SPECTAVI_RANSAC_SEED")) return (uint32_t)strtoul(e, nullptr, 0);
+  return std::random_device{}();
+}
+
+int check_fit_args(const double *x0, const double *x1, int npt, int max_tries) {
+  if (!x0 || !x1) return set_error(SPV_ERR_INVALID, "null pointer");
+  // RansacFitter's constructor, src/RansacFitter.h:146-149
+  if (npt < 10) return set_error(SPV_ERR_INVALID, "Supplied less than 10 point matches, unsupported.");
+  if (max_tries < 0) return set_error(SPV_ERR_INVALID, "negative maximum_tries");
+  return SPV_OK;
+}
+
+// samples != NULL: the 7-subsets of the tries, int32[max_tries,7]; otherwise drawn from `seed`.
+int host_ransac_fit(const double *x0, const double *x1, int npt, double required_percent, double max_error,
+                    int max_tries, int find_best, double ratio_allowed, const int32_t *samples, uint64_t seed,
+                    int32_t *success, double *essential, double *camera, double *inlier_percent,
+                    int32_t *inlier_idx, int32_t *n_inliers, int32_t *best_try, int32_t *best_root,
+                    int32_t *tries_run) {
+  SPV_TRY(check_fit_args(x0, x1, npt, max_tries));
+  if (!success || !essential || !camera || !inlier_percent || !inlier_idx || !n_inliers)
+    return set_error(SPV_ERR_INVALID, "null pointer");
+  SPV_TRY(ensure_device());
+  const int batch = std::min(ransac_fit_batch_limit(npt), std::max(max_tries, 1));
+  const size_t wsb = ransac_fit_workspace_bytes(batch, npt);
+  const size_t ib = (size_t)npt * 3 * sizeof(double);
+  DevBuf dx, dxp, ws;
+  SPV_TRY(dx.alloc(ib));
+  SPV_TRY(dxp.alloc(ib));
+  SPV_TRY(ws.alloc(wsb));
+  hipStream_t st = hipStreamPerThread;
+  SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x0, ib, hipMemcpyHostToDevice, st));
+  SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, x1, ib, hipMemcpyHostToDevice, st));
+  std::mt19937 gen(samples ? 0u : ransac_seed(seed));
+  auto next = [&](int first, int n, int *dst) {
+    if (samples) {
+      memcpy(dst, samples + (size_t)first * 7, (size_t)n * 7 * sizeof(int));
+    } else {
+      for (int t = 0; t < n; ++t) floyd_sample(gen, npt, dst + 7 * (size_t)t);
+    }
+  };
+  std::vector<unsigned char> mask((size_t)npt, 0);
+  int ok = 0, ninl = 0, bt = -1, br = -1, ran = 0;
+  SPV_TRY(ransac_fit_run(dx.as<double>(), dxp.as<double>(), npt, required_percent, max_error, max_tries, find_best,
+                         ratio_allowed, next, &ok, essential, camera, &ninl, mask.data(), &bt, &br, &ran, ws.p, wsb,
+                         batch, st));
+  *success = ok;
+  *inlier_percent = (double)ninl / (double)npt;
+  int n = 0;
+  if (bt >= 0)
+    for (int i = 0; i < npt; ++i)
+      if (mask[i]) inlier_idx[n++] = i;
+  if (n != ninl) return set_error(SPV_ERR_HIP, "inlier list has %d entries, the count was %d", n, ninl);
+  *n_inliers = n;
+  if (best_try) *best_try = bt;
+  if (best_root) *best_root = br;
+  if (tries_run) *tries_run = ran;
+  return SPV_OK;
+}
+
 int host_ratio(const uint64_t *idx, const void *dist, int dist_is_float, int yrows, double min_ratio,
                int32_t *matches, int32_t *count) {
   if (yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
@@ -1473,6 +1574,99 @@ int spv_ransac_process_candidates(const double *Fs, int nF, const double *x0, co
                                best_camera, best_P, gate_ratio, E, counts4, inlier_mask);
   });
 }
+int spv_seven_point(const double *x, const double *xp, int n, int32_t *nroot, double *Fs, double *basis) {
+  clear_error();
+  return host_guard([&] { return host_seven_point(x, xp, n, nroot, Fs, basis); });
+}
+int spv_seven_point_device(const double *d_x, const double *d_xp, int n, double *d_Fs, int32_t *d_nroot,
+                           double *d_basis, void *stream) {
+  clear_error();
+  return guard([&] { return seven_point_run(d_x, d_xp, n, d_Fs, d_nroot, d_basis, static_cast<hipStream_t>(stream)); });
+}
+int spv_ransac_sample(unsigned long long seed, int npt, int ntries, int32_t *samples) {
+  clear_error();
+  if (npt < 10) return set_error(SPV_ERR_INVALID, "Supplied less than 10 point matches, unsupported.");
+  if (ntries < 0 || (ntries > 0 && !samples)) return set_error(SPV_ERR_INVALID, "bad arguments");
+  std::mt19937 gen(ransac_seed(seed));
+  for (int t = 0; t < ntries; ++t) floyd_sample(gen, npt, samples + 7 * (size_t)t);
+  return SPV_OK;
+}
+int spv_ransac_fit(const double *x0, const double *x1, int npt, double required_percent_inliers,
+                   double reprojection_error_allowed, int maximum_tries, int find_best_even_in_failure,
+                   double singular_value_ratio_allowed, unsigned long long seed, int32_t *success,
+                   double *essential, double *camera, double *inlier_percent, int32_t *inlier_idx,
+                   int32_t *n_inliers, int32_t *best_try, int32_t *best_root, int32_t *tries_run) {
+  clear_error();
+  return host_guard([&] {
+    return host_ransac_fit(x0, x1, npt, required_percent_inliers, reprojection_error_allowed, maximum_tries,
+                           find_best_even_in_failure, singular_value_ratio_allowed, nullptr, seed, success, essential,
+                           camera, inlier_percent, inlier_idx, n_inliers, best_try, best_root, tries_run);
+  });
+}
+int spv_ransac_fit_samples(const double *x0, const double *x1, int npt, double required_percent_inliers,
+                           double reprojection_error_allowed, const int32_t *samples, int ntries,
+                           int find_best_even_in_failure, double singular_value_ratio_allowed, int32_t *success,
+                           double *essential, double *camera, double *inlier_percent, int32_t *inlier_idx,
+                           int32_t *n_inliers, int32_t *best_try, int32_t *best_root, int32_t *tries_run) {
+  clear_error();
+  if (ntries > 0 && !samples) return set_error(SPV_ERR_INVALID, "null samples");
+  return host_guard([&] {
+    return host_ransac_fit(x0, x1, npt, required_percent_inliers, reprojection_error_allowed, ntries,
+                           find_best_even_in_failure, singular_value_ratio_allowed, samples, 0, success, essential,
+                           camera, inlier_percent, inlier_idx, n_inliers, best_try, best_root, tries_run);
+  });
+}
+
+// ---- the reference's own symbols for this path (src/Spectavi.cpp:14-36, :70-87) ------------
+void seven_point_algorithm(const double *x, const double *xp, int *nroot, double *dst) {
+  clear_error();
+  if (!nroot || !dst) {
+    set_error(SPV_ERR_INVALID, "null pointer");
+    return;
+  }
+  *nroot = 0;
+  int32_t nr = 0;
+  double Fs[27];
+  if (host_guard([&] { return host_seven_point(x, xp, 1, &nr, Fs, nullptr); }) != SPV_OK) return;
+  *nroot = nr;
+  memcpy(dst, Fs, (size_t)nr * 9 * sizeof(double));  // only the roots found are written, as in the reference
+}
+
+void ransac_fitter(const double *x0, const double *x1, int npt, double required_percent_inliers,
+                   double reprojection_error_allowed, int maximum_tries, bool find_best_even_in_failure,
+                   double singular_value_ratio_allowed, bool progressbar, bool *success, NdArray *essential,
+                   NdArray *camera, double *inlier_percent, NdArray *inlier_idx) {
+  (void)progressbar;  // the reference draws a text bar on stdout per try; tries run in batches here
+  clear_error();
+  if (!success || !inlier_percent) {
+    set_error(SPV_ERR_INVALID, "null pointer");
+    return;
+  }
+  *success = false;
+  *inlier_percent = 0.0;
+  host_guard([&] {
+    SPV_TRY(check_fit_args(x0, x1, npt, maximum_tries));
+    int32_t ok = 0, n = 0, bt = -1;
+    double F[9], P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, pct = 0.0;  // Camera(): Identity(3,4), src/Camera.h:27
+    std::vector<int32_t> idx((size_t)npt);
+    SPV_TRY(host_ransac_fit(x0, x1, npt, required_percent_inliers, reprojection_error_allowed, maximum_tries,
+                            find_best_even_in_failure ? 1 : 0, singular_value_ratio_allowed, nullptr, 0, &ok, F, P, &pct,
+                            idx.data(), &n, &bt, nullptr, nullptr));
+    // ndarray_copy_matrix of the fitter's members (src/Spectavi.cpp:82-86): an untouched
+    // m_best_fit_essential_matrix / m_inlier_idx is a 0 x 0 matrix
+    const bool found = bt >= 0;
+    SPV_TRY(alloc_out(essential, found ? 3 : 0, found ? 3 : 0, sizeof(double)));
+    if (found) memcpy(essential->m_data, F, sizeof(F));
+    SPV_TRY(alloc_out(camera, 3, 4, sizeof(double)));
+    memcpy(camera->m_data, P, sizeof(P));
+    SPV_TRY(alloc_out(inlier_idx, found ? (size_t)n : 0, found ? 1 : 0, sizeof(int32_t)));
+    if (found && n > 0) memcpy(inlier_idx->m_data, idx.data(), (size_t)n * sizeof(int32_t));
+    *success = ok != 0;
+    *inlier_percent = pct;
+    return (int)SPV_OK;
+  });
+}
+
 size_t spv_ransac_workspace_bytes(int nF, long long npt, int want_mask) {
   return (nF < 0 || npt < 0) ? 0 : ransac_workspace_bytes(nF, npt, want_mask != 0);
 }

@@ -6,6 +6,7 @@
 #include <stddef.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -121,5 +122,18 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
                        int *d_success, int *d_inlier_count, int *d_best_cam, double *d_best_P, double *d_ratio,
                        double *d_E, int *d_counts4, unsigned char *d_mask, void *d_ws, size_t ws_bytes,
                        hipStream_t stream);
+
+// ---- seven-point solver and the RANSAC loop around the candidate processing (ransac.hip) ----
+// d_x, d_xp double[n,7,2] euclidean; d_Fs double[n,3,9] (NaN in the slots of missing roots);
+// d_nroot int[n] and d_basis double[n,2,9] may be NULL
+int seven_point_run(const double *d_x, const double *d_xp, int n, double *d_Fs, int *d_nroot, double *d_basis,
+                    hipStream_t stream);
+int ransac_fit_batch_limit(long long npt);  // tries per batch for this many correspondences
+size_t ransac_fit_workspace_bytes(int batch, long long npt);
+int ransac_fit_run(const double *d_x0, const double *d_x1, long long npt, double required_percent,
+                   double max_error, int max_tries, int find_best, double ratio_allowed,
+                   const std::function<void(int, int, int *)> &next_samples, int *success, double *essential,
+                   double *camera, int *n_inliers, unsigned char *inlier_mask, int *best_try, int *best_root,
+                   int *tries_run, void *d_ws, size_t ws_bytes, int batch, hipStream_t stream);
 
 }  // namespace spv

@@ -623,8 +623,8 @@ __device__ __forceinline__ void mat3_mul(const double (&A)[3][3], const double (
     }
 }
 
-// One lane per candidate F: gate, E, the four cameras.  cams double[nF,4,12]; gated candidates get
-// NaN cameras (the scoring kernel skips them) and gated[f] = 1.
+// One lane per candidate F: gate, E, the four cameras.  cams double[nF,4,12]; gated candidates (and
+// candidates with a NaN entry) get NaN cameras (the scoring kernel skips them) and gated[f] = 1.
 __global__ __launch_bounds__(kDltThreads) void essential_cameras_kernel(
     const double *__restrict__ Fs, int nF, double ratio_allowed, double *__restrict__ cams,
     double *__restrict__ ratio_out, double *__restrict__ E_out, int *__restrict__ gated) {
@@ -633,12 +633,18 @@ __global__ __launch_bounds__(kDltThreads) void essential_cameras_kernel(
   double F[3][3], U[3][3], S[3], V[3][3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = Fs[(size_t)f * 9 + i];
+  // A candidate with a NaN entry is no candidate (the empty root slots of the seven-point kernel
+  // arrive this way; the reference has no such input): rejected like a gated one.
+  bool has_nan = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) has_nan |= (F[i / 3][i % 3] != F[i / 3][i % 3]);
   jacobi_svd3(F, U, S, V);
-  const double ratio = fabs(S[0] - S[1]) / (fabs(S[0] + S[1]) / 2.);
-  if (ratio_out) ratio_out[f] = ratio;
   const double nan = __builtin_nan("");
+  const double ratio = has_nan ? nan : fabs(S[0] - S[1]) / (fabs(S[0] + S[1]) / 2.);
+  if (ratio_out) ratio_out[f] = ratio;
   double *out = cams + (size_t)f * 48;
-  if (ratio > ratio_allowed) {  // src/RansacFitter.h:51-53 (a NaN ratio is not gated there either)
+  // src/RansacFitter.h:51-53 (a NaN ratio of finite entries, e.g. F = 0, is not gated there either)
+  if (has_nan || ratio > ratio_allowed) {
     gated[f] = 1;
 #pragma unroll
     for (int i = 0; i < 48; ++i) out[i] = nan;

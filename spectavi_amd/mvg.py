@@ -2,8 +2,9 @@
 ``spectavi_amd.mvg``
 ====================
 Multi-view-geometry front-end: the batched DLT triangulator of the reference's
-``spectavi.mvg`` (reference spectavi/mvg.py:259-306), bound to the gfx950 build
-of ``libspectavi.so``.
+``spectavi.mvg`` (reference spectavi/mvg.py:259-306) and its callers, the seven-point
+algorithm and the RANSAC fitter (reference spectavi/mvg.py:112-248), bound to the
+gfx950 build of ``libspectavi.so``.
 """
 import ctypes as ct
 
@@ -11,6 +12,7 @@ import numpy as np
 from numpy.ctypeslib import ndpointer
 
 from spectavi_amd._lib import clib, check
+from spectavi_amd.ndarray import NdArray
 
 
 def hnormalize(x):
@@ -171,3 +173,188 @@ def process_fundamental_matrices(Fs, x0, x1, options={'required_percent_inliers'
     if return_mask:
         ret['inlier_mask'] = mask.astype(bool)
     return ret
+
+
+# ==================================================================================
+# seven_point_algorithm / ransac_fitter (reference spectavi/mvg.py:112-248)
+# ==================================================================================
+_seven_point_algorithm = clib.seven_point_algorithm
+_seven_point_algorithm.restype = None
+_seven_point_algorithm.argtypes = [ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                                   ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                                   ct.POINTER(ct.c_int),
+                                   ndpointer(ct.c_double, flags="C_CONTIGUOUS")]
+
+
+def seven_point_algorithm(x, xp):
+    """
+    The fundamental matrices through seven correspondences (reference spectavi/mvg.py:237-248).
+
+    x, xp : float64 [7,2] euclidean or [7,3] homogeneous image points.
+    Returns float64 [3*nroot, 3]: the nroot (0..3) solutions stacked, each with xp^T F x = 0.
+    """
+    if not (x.shape[0] == 7 and xp.shape[0] == 7):
+        raise TypeError('Must be 7 points.')
+    if not (x.shape[1] == 2 and xp.shape[1] == 2):
+        x, xp = hnormalize(x), hnormalize(xp)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    xp = np.ascontiguousarray(xp, dtype=np.float64)
+    dst = np.empty((3, 3, 3))
+    nroot = ct.c_int()
+    _seven_point_algorithm(x, xp, ct.byref(nroot), dst)
+    check()
+    nroot = nroot.value
+    return np.vstack(dst[:nroot]) if nroot else np.empty((0, 3))
+
+
+_spv_seven_point = clib.spv_seven_point
+_spv_seven_point.restype = ct.c_int
+_spv_seven_point.argtypes = [_f64, _f64, ct.c_int, _i32, _f64, ct.c_void_p]
+
+
+def seven_point_batch(x, xp, return_basis=False):
+    """
+    Seven-point algorithm for n independent 7-subsets at once.
+
+    x, xp : float64 [n,7,2] euclidean.  Returns (nroot int32 [n], Fs float64 [n,3,3,3]) -- slots
+    of missing roots are NaN -- and, with `return_basis`, the null-space pair [n,2,3,3].
+    """
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    xp = np.ascontiguousarray(xp, dtype=np.float64)
+    if not (x.ndim == 3 and x.shape[1:] == (7, 2) and xp.shape == x.shape):
+        raise TypeError('x, xp must be [n,7,2].')
+    n = x.shape[0]
+    nroot = np.zeros(n, np.int32)
+    Fs = np.zeros((n, 3, 3, 3))
+    basis = np.zeros((n, 2, 3, 3)) if return_basis else None
+    check(_spv_seven_point(x.reshape(-1), xp.reshape(-1), n, nroot, Fs.reshape(-1),
+                           basis.ctypes.data if return_basis else None))
+    return (nroot, Fs, basis) if return_basis else (nroot, Fs)
+
+
+_ransac_fitter = clib.ransac_fitter
+_ransac_fitter.restype = None
+_ransac_fitter.argtypes = [ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                           ndpointer(ct.c_double, flags="C_CONTIGUOUS"),
+                           ct.c_int,
+                           ct.c_double,
+                           ct.c_double,
+                           ct.c_int,
+                           ct.c_bool,
+                           ct.c_double,
+                           ct.c_bool,
+                           ct.POINTER(ct.c_bool),
+                           ct.POINTER(NdArray),
+                           ct.POINTER(NdArray),
+                           ct.POINTER(ct.c_double),
+                           ct.POINTER(NdArray), ]
+
+
+def ransac_fitter(x0, x1, options={'required_percent_inliers': .9,
+                                   'reprojection_error_allowed': .5,
+                                   'maximum_tries': 500,
+                                   'find_best_even_in_failure': True,
+                                   'singular_value_ratio_allowed': 3e-2,
+                                   'progressbar': False}):
+    """
+    Fit a two-view geometry to tentatively corresponding points by RANSAC
+    (reference spectavi/mvg.py:131-221; same option names and defaults).
+
+    x0, x1 : float64 [npt,3] homogeneous normalised coordinates, npt >= 10.
+    Returns the reference's dict: success, essential [3,3] (the winning seven-point solution),
+    camera [3,4] (second camera; the first is [I | 0]), inlier_percent, inlier_idx int32 [n,1].
+    If no model was kept essential and inlier_idx are empty and camera is [I | 0].
+    Set SPECTAVI_RANSAC_SEED for reproducible subsets; `progressbar` is ignored.
+    """
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    if not (x0.ndim == 2 and x0.shape == x1.shape and x0.shape[1] == 3):
+        raise TypeError('Coords must be homogenous [npt,3] pairs.')
+    npt = x0.shape[0]
+    if npt < 10:
+        raise ValueError('Supplied less than 10 point matches, unsupported.')
+    success = ct.c_bool()
+    essential = NdArray()
+    camera = NdArray()
+    inlier_idx = NdArray(dtype='int32')
+    inlier_percent = ct.c_double()
+    _ransac_fitter(x0, x1, npt, options['required_percent_inliers'],
+                   options['reprojection_error_allowed'],
+                   options['maximum_tries'],
+                   options['find_best_even_in_failure'],
+                   options['singular_value_ratio_allowed'],
+                   options.get('progressbar', False),
+                   ct.byref(success),
+                   ct.byref(essential),
+                   ct.byref(camera),
+                   ct.byref(inlier_percent),
+                   ct.byref(inlier_idx))
+    check()
+    return {'success': success.value,
+            'essential': essential.asarray(),
+            'camera': camera.asarray(),
+            'inlier_percent': inlier_percent.value,
+            'inlier_idx': inlier_idx.asarray(), }
+
+
+_spv_ransac_sample = clib.spv_ransac_sample
+_spv_ransac_sample.restype = ct.c_int
+_spv_ransac_sample.argtypes = [ct.c_ulonglong, ct.c_int, ct.c_int, _i32]
+
+
+def ransac_sample(seed, npt, ntries):
+    """The 7-subsets int32 [ntries,7] that `ransac_fit(seed=seed)` evaluates (drawn as the reference's
+    floyd_sample draws them, reference src/RansacFitter.h:120-132, from one mt19937)."""
+    samples = np.zeros((ntries, 7), np.int32)
+    check(_spv_ransac_sample(int(seed), int(npt), int(ntries), samples.reshape(-1)))
+    return samples
+
+
+_fit_out = [ct.POINTER(ct.c_int32), _f64, _f64, ct.POINTER(ct.c_double), _i32, ct.POINTER(ct.c_int32),
+            ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]
+_spv_ransac_fit = clib.spv_ransac_fit
+_spv_ransac_fit.restype = ct.c_int
+_spv_ransac_fit.argtypes = [_f64, _f64, ct.c_int, ct.c_double, ct.c_double, ct.c_int, ct.c_int, ct.c_double,
+                            ct.c_ulonglong] + _fit_out
+_spv_ransac_fit_samples = clib.spv_ransac_fit_samples
+_spv_ransac_fit_samples.restype = ct.c_int
+_spv_ransac_fit_samples.argtypes = [_f64, _f64, ct.c_int, ct.c_double, ct.c_double, _i32, ct.c_int, ct.c_int,
+                                    ct.c_double] + _fit_out
+
+
+def ransac_fit(x0, x1, required_percent_inliers=.9, reprojection_error_allowed=.5, maximum_tries=500,
+               find_best_even_in_failure=True, singular_value_ratio_allowed=3e-2, seed=0, samples=None):
+    """
+    `ransac_fitter` with plain outputs and explicit control of the subsets: `samples` int32 [ntries,7]
+    (then `maximum_tries` and `seed` are ignored) or `seed` (0 = SPECTAVI_RANSAC_SEED / random).
+
+    Returns the `ransac_fitter` dict (essential / camera None and inlier_idx empty when no model was
+    kept) plus best_try, best_root (which try and which of its roots won; -1 if none) and tries_run.
+    """
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    if not (x0.ndim == 2 and x0.shape == x1.shape and x0.shape[1] == 3):
+        raise TypeError('Coords must be homogenous [npt,3] pairs.')
+    npt = x0.shape[0]
+    if npt < 10:
+        raise ValueError('Supplied less than 10 point matches, unsupported.')
+    ok, n, bt, br, ran = ct.c_int32(0), ct.c_int32(0), ct.c_int32(-1), ct.c_int32(-1), ct.c_int32(0)
+    pct = ct.c_double(0.0)
+    F, P, idx = np.zeros(9), np.zeros(12), np.zeros(npt, np.int32)
+    outs = (ct.byref(ok), F, P, ct.byref(pct), idx, ct.byref(n), ct.byref(bt), ct.byref(br), ct.byref(ran))
+    if samples is not None:
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        if not (samples.ndim == 2 and samples.shape[1] == 7):
+            raise TypeError('samples must be [ntries,7].')
+        check(_spv_ransac_fit_samples(x0, x1, npt, float(required_percent_inliers), float(reprojection_error_allowed),
+                                      samples.reshape(-1), samples.shape[0], int(bool(find_best_even_in_failure)),
+                                      float(singular_value_ratio_allowed), *outs))
+    else:
+        check(_spv_ransac_fit(x0, x1, npt, float(required_percent_inliers), float(reprojection_error_allowed),
+                              int(maximum_tries), int(bool(find_best_even_in_failure)),
+                              float(singular_value_ratio_allowed), int(seed), *outs))
+    found = bt.value >= 0
+    return {'success': bool(ok.value), 'essential': F.reshape(3, 3) if found else None,
+            'camera': P.reshape(3, 4) if found else None, 'inlier_percent': float(pct.value),
+            'inlier_idx': idx[:n.value].copy(), 'best_try': bt.value, 'best_root': br.value,
+            'tries_run': ran.value}

@@ -230,3 +230,17 @@ def test_gather_mode_api_without_gpu():
     assert clib.spv_set_gather_mode(7) == SPV_ERR_INVALID
     for mode in (1, 0, -1):
         assert clib.spv_set_gather_mode(mode) == 0
+
+
+def test_ransac_sample_is_the_reference_draw():
+    """floyd_sample (reference src/RansacFitter.h:120-132): seven distinct rows per try, values in
+    [1, npt-1] (the reference's range starts at 1), reproducible per seed.  Host-only logic: runs without a GPU."""
+    from spectavi_amd import mvg
+    for npt in (10, 11, 50, 100000):
+        s = mvg.ransac_sample(5, npt, 400)
+        assert s.shape == (400, 7) and s.min() >= 1 and s.max() <= npt - 1
+        assert all(len(set(r)) == 7 for r in s.tolist())
+        assert np.array_equal(s, mvg.ransac_sample(5, npt, 400))
+        assert not np.array_equal(s, mvg.ransac_sample(6, npt, 400))
+    with pytest.raises(Exception):
+        mvg.ransac_sample(1, 9, 1)

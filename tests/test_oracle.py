@@ -287,3 +287,65 @@ def test_essential_to_cameras_and_candidate_processing_oracle(oracle):
         g = oracle.process_fundamental_matrix(F, x0, x1, 3e-2, .9, 1e-3, True)
         assert abs(g["gate_ratio"] - abs(s[0] - s[1]) / (abs(s[0] + s[1]) / 2)) < 1e-12
         assert g["success"] == (False if g["gate_ratio"] > 3e-2 else g["success"]) and (g["gate_ratio"] <= 3e-2 or (g["counts4"] == -1).all())
+
+
+def test_seven_point_oracle_reference_properties_and_numpy(oracle):
+    """Pins oracle/oracle_ransac.cpp::seven_point: the reference's own test properties
+    (test/test_mvg.py:127-160) and the independent LAPACK + numpy.roots statement."""
+    from tests import mvg_checks as mc
+    rng = np.random.default_rng(0x7b7)
+    for it in range(300):
+        x, xp = rng.standard_normal((7, 3)), rng.standard_normal((7, 3))
+        xe, xpe = x[:, :2] / x[:, 2:], xp[:, :2] / xp[:, 2:]
+        Fs, basis = oracle.seven_point(xe, xpe, return_basis=True)
+        assert len(Fs) in (0, 1, 2, 3)
+        # the basis is orthonormal and lies in the null space of the 7 x 9 system
+        B = basis.reshape(2, 9)
+        A = mc.seven_point_rows(xe, xpe)
+        assert np.abs(B @ B.T - np.eye(2)).max() < 1e-13
+        assert np.abs(A @ B.T).max() <= 1e-12 * np.abs(A).max()
+        scale = max(1.0, np.abs(A).max())
+        for F in Fs:
+            assert mc.epipolar_residual(F, xe, xpe) < 1e-10 * scale  # test_mvg.py:139-141 (there unscaled)
+        mc.check_seven_point(Fs, xe, xpe, "oracle case %d" % it)
+    # reconstruction, test_mvg.py:143-160
+    for it in range(100):
+        P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+        P1 = rng.standard_normal((3, 4))
+        F0 = mc.skew(P1[:, 3]) @ P1 @ (P0.T @ np.linalg.inv(P0 @ P0.T))
+        X = rng.standard_normal((7, 4))
+        x0, x1 = X @ P0.T, X @ P1.T
+        Fs = oracle.seven_point(x0[:, :2] / x0[:, 2:], x1[:, :2] / x1[:, 2:])
+        assert any(np.std(F / F0) < 1e-8 for F in Fs), it
+
+
+def test_ransac_fit_oracle(oracle):
+    """oracle_ransac_fit: the reference's own RANSAC test (test/test_mvg.py:38-91: success, essential
+    recovered to std(rE / E) < 1e-2 with the reference's options), then a contaminated scene: the
+    inliers are the uncontaminated correspondences, the winning subset is clean, and the serial
+    update rule holds (nothing after the first success is looked at)."""
+    from tests import mvg_checks as mc
+    rng = np.random.default_rng(0xdeadbeef)
+    x0, x1, E = mc.reference_ransac_scene(rng)
+    samples = np.stack([rng.choice(np.arange(1, 200), 7, replace=False) for _ in range(200)]).astype(np.int32)
+    r = oracle.ransac_fit(x0, x1, samples, required_percent_inliers=0.9, reprojection_error_allowed=0.5,
+                          find_best_even_in_failure=False, singular_value_ratio_allowed=3e-2)
+    assert r["success"] and mc.essential_agrees(r["essential"], E) < 1e-2
+
+    x0, x1, E, out_idx = mc.two_view_scene(rng, npt=200, outlier_fraction=0.25)
+    kw = dict(reprojection_error_allowed=1e-3, find_best_even_in_failure=False)
+    r = oracle.ransac_fit(x0, x1, samples[:80], required_percent_inliers=0.7, **kw)
+    assert r["success"] and r["best_try"] >= 0
+    assert mc.essential_agrees(r["essential"], E) < 1e-6
+    assert r["inlier_percent"] == len(r["inlier_idx"]) / 200.0 > 0.7
+    assert np.array_equal(r["inlier_idx"], np.setdiff1d(np.arange(200), out_idx))
+    assert not np.intersect1d(samples[r["best_try"]], out_idx).size
+    r2 = oracle.ransac_fit(x0, x1, samples[:r["best_try"] + 1], required_percent_inliers=0.7, **kw)
+    assert r2["best_try"] == r["best_try"] and r2["best_root"] == r["best_root"]
+    assert np.array_equal(r2["inlier_idx"], r["inlier_idx"])
+    # an unreachable requirement: nothing is kept without find_best, the best is kept with it
+    r3 = oracle.ransac_fit(x0, x1, samples[:40], required_percent_inliers=0.99, **kw)
+    assert not r3["success"] and r3["best_try"] == -1 and r3["essential"] is None and r3["inlier_percent"] == 0
+    kw["find_best_even_in_failure"] = True
+    r4 = oracle.ransac_fit(x0, x1, samples[:40], required_percent_inliers=0.99, **kw)
+    assert not r4["success"] and r4["best_try"] >= 0 and 0 < r4["inlier_percent"] <= 0.75
