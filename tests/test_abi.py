@@ -143,7 +143,8 @@ def test_frontend_signatures_match_reference_source():
     mtree, mfun = ref_functions(os.path.join(ref_dir, "mvg.py"))
     for mod, funs, names in ((feature, ffun, ["nn_bruteforcel1k2", "nn_cascading_hash",
                                               "normalize_to_ubyte_and_multiple_16_dim"]),
-                             (mvg, mfun, ["dlt_triangulate", "dlt_reprojection_error", "hnormalize"])):
+                             (mvg, mfun, ["dlt_triangulate", "dlt_reprojection_error", "hnormalize",
+                                          "ransac_fitter", "seven_point_algorithm"])):
         for name in names:
             sig = inspect.signature(getattr(mod, name))
             ours = list(sig.parameters)
@@ -154,6 +155,8 @@ def test_frontend_signatures_match_reference_source():
     assert len(feature._nn_cascading_hash.argtypes) == ref_argtypes_len(ftree, "_nn_cascading_hash") == 11
     assert len(mvg._dlt_triangulate.argtypes) == ref_argtypes_len(mtree, "_dlt_triangulate") == 6
     assert len(mvg._dlt_reprojection_error.argtypes) == ref_argtypes_len(mtree, "_dlt_reprojection_error") == 6
+    assert len(mvg._ransac_fitter.argtypes) == ref_argtypes_len(mtree, "_ransac_fitter") == 14
+    assert len(mvg._seven_point_algorithm.argtypes) == ref_argtypes_len(mtree, "_seven_point_algorithm") == 4
 
 
 def test_only_the_declared_api_is_exported():

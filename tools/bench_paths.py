@@ -297,13 +297,55 @@ def next_rows(steps, warmup):
                       "config": {"workload": "%d x 132 float32" % rows}, "dtype": "f32", "data": "synthetic"}), flush=True)
 
 
+def ransac_fit():
+    """The RANSAC loop itself (seven-point solve + candidate processing + best-model rule) through the
+    host-pointer entry: all tries evaluated (requirement out of reach) for the rate, then the time to
+    the first success on the same scene; the oracle's serial loop timed beside it on a few tries."""
+    from spectavi_amd import mvg
+    from tests import mvg_checks as mc
+    rng = np.random.default_rng(21)
+    for npt, tries in ((500, 40000), (2000, 20000), (20000, 4000)):
+        x0, x1, E, out_idx = mc.two_view_scene(rng, npt=npt, outlier_fraction=0.4, noise=1e-4)
+        kw = dict(reprojection_error_allowed=1e-3, singular_value_ratio_allowed=3e-2)
+        mvg.ransac_fit(x0, x1, required_percent_inliers=0.999, maximum_tries=300, seed=1, **kw)  # warm-up
+        spv.profile_reset()
+        spv.profile_enable(True)
+        t0 = time.perf_counter()
+        r = mvg.ransac_fit(x0, x1, required_percent_inliers=0.999, maximum_tries=tries, seed=2, **kw)
+        dt = time.perf_counter() - t0
+        spv.profile_enable(False)
+        assert r["tries_run"] == tries and not r["success"]
+        parts = {k: spv.profile_read(k)[1] for k in ("seven_point", "ransac_cameras", "dlt_score", "ransac_reduce")}
+        # time to the first model with more than half of the correspondences as inliers
+        t_succ, n_succ = [], []
+        for seed in range(3, 11):
+            t0 = time.perf_counter()
+            rs = mvg.ransac_fit(x0, x1, required_percent_inliers=0.5, maximum_tries=tries, seed=seed, **kw)
+            t_succ.append(time.perf_counter() - t0)
+            n_succ.append(rs["tries_run"] if rs["success"] else -1)
+        from oracle import oracle as o
+        cpu_tries = 2000 if npt <= 2000 else 400  # a try costs microseconds when the gate rejects it, 4 x npt SVDs when not
+        samples = mvg.ransac_sample(2, npt, cpu_tries)
+        t0 = time.perf_counter()
+        o.ransac_fit(x0, x1, samples, required_percent_inliers=0.999, **kw)
+        cpu_dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "RANSAC fit (7-subset -> seven-point -> 3 candidates x 4 cameras x all correspondences -> best model), tries/s",
+                          "value": tries / dt, "unit": "tries/s", "ms_total": dt * 1e3, "kernel_ms": parts,
+                          "config": {"workload": "%d correspondences, 40 %% outliers, %d tries, none succeeds" % (npt, tries)},
+                          "first_success": {"required_percent_inliers": 0.5, "ms": [round(t * 1e3, 2) for t in t_succ],
+                                            "tries_run": n_succ},
+                          "cpu_baseline": {"value": cpu_tries / cpu_dt, "unit": "tries/s", "cores": 1, "kind": "port",
+                                           "sample": "%d tries of the same scene, serial loop of oracle_ransac.cpp" % cpu_tries},
+                          "dtype": "f64", "data": "synthetic"}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--npt", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma list of: cascade,dlt,next,shapes,e2e (default all)")
+    ap.add_argument("--only", default="", help="comma list of: cascade,dlt,next,shapes,e2e,fit (default all)")
     a = ap.parse_args()
     want = set(filter(None, a.only.split(",")))
     if not want or "cascade" in want:
@@ -317,3 +359,5 @@ if __name__ == "__main__":
         l1k2_shapes(a.steps, a.warmup)
     if not want or "e2e" in want:
         end_to_end()
+    if not want or "fit" in want:
+        ransac_fit()
