@@ -243,17 +243,101 @@ def fuzz_normalize(seed, budget, only_case=None):
     return n
 
 
+def fuzz_seven_point(seed, budget, only_case=None):
+    """Batches of random 7-subsets (heavy-tailed hnormalized Gaussians, consistent two-view subsets,
+    near-degenerate ones): every F parallel to an oracle solution and a LAPACK + numpy.roots solution,
+    root counts equal away from a vanishing discriminant, the null-space pair spanning the oracle's."""
+    from tests import mvg_checks as mc
+    t0, n = time.time(), 0 if only_case is None else only_case
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, 6, n])
+        nb = int(rng.choice([1, 63, 64, 65, 200]))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            a, b = rng.standard_normal((nb, 7, 3)), rng.standard_normal((nb, 7, 3))
+            x, xp = a[..., :2] / a[..., 2:], b[..., :2] / b[..., 2:]
+        elif kind == 1:
+            x, xp = rng.standard_normal((nb, 7, 2)) * 10.0 ** rng.uniform(-3, 3), rng.standard_normal((nb, 7, 2))
+        else:
+            xs, xps = [], []
+            for _ in range(nb):
+                x0, x1, _, _ = mc.two_view_scene(rng, npt=7, noise=0.0 if kind == 2 else 10.0 ** rng.uniform(-8, -2))
+                xs.append(x0[:, :2] / x0[:, 2:])
+                xps.append(x1[:, :2] / x1[:, 2:])
+            x, xp = np.array(xs), np.array(xps)
+        nroot, Fs, basis = mvg.seven_point_batch(x, xp, return_basis=True)
+        for i in range(nb):
+            k = int(nroot[i])
+            oFs, ob = o.seven_point(x[i], xp[i], return_basis=True)
+            B, OB = basis[i].reshape(2, 9), ob.reshape(2, 9)
+            bad = None
+            if not np.abs(B.T @ B - OB.T @ OB).max() < 1e-9:
+                bad = "null-space plane differs from the oracle's"
+            _, margin, lead = mc.numpy_seven_point(x[i], xp[i])
+            clear = margin > 1e-6 and lead > 1e-10
+            if bad is None and clear and k != len(oFs):
+                bad = "%d roots, oracle %d" % (k, len(oFs))
+            if bad is None and clear:
+                for F in Fs[i, :k]:
+                    if max((mc.parallel(F, G) for G in oFs), default=0.0) < 1 - 1e-9:
+                        bad = "an F is not an oracle solution"
+                try:
+                    mc.check_seven_point(Fs[i, :k], x[i], xp[i], "fuzz")
+                except AssertionError as e:
+                    bad = str(e)
+            if bad:
+                raise SystemExit("SEVEN-POINT MISMATCH case=%d kind=%d item=%d of %d: %s" % (n, kind, i, nb, bad))
+        n += 1
+        if only_case is not None:
+            break
+    return n
+
+
+def fuzz_ransac_fit(seed, budget, only_case=None):
+    """Whole fits on random contaminated scenes with the subsets handed to both sides: the winning
+    try, root, inlier list and share equal the oracle's serial loop."""
+    from tests import mvg_checks as mc
+    t0, n = time.time(), 0 if only_case is None else only_case
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, 7, n])
+        npt = int(rng.choice([10, 11, 64, 65, 300, rng.integers(12, 1500)]))
+        frac = float(rng.choice([0.0, 0.1, 0.3, 0.5]))
+        x0, x1, E, out_idx = mc.two_view_scene(rng, npt=npt, outlier_fraction=frac)
+        tries = int(rng.choice([1, 7, 255, 256, 257, 700]))
+        samples = mvg.ransac_sample(int(rng.integers(1, 1 << 30)), npt, tries)
+        kw = dict(required_percent_inliers=float(rng.choice([0.3, 1.0 - frac - 0.05, 0.999])),
+                  reprojection_error_allowed=1e-3, find_best_even_in_failure=bool(rng.integers(0, 2)),
+                  singular_value_ratio_allowed=float(rng.choice([3e-2, 1e-3, 0.5])))
+        oo = o.ransac_fit(x0, x1, samples, **kw)
+        dd = mvg.ransac_fit(x0, x1, samples=samples, **kw)
+        same = (dd['success'] == oo['success'] and dd['best_try'] == oo['best_try'] and dd['best_root'] == oo['best_root']
+                and dd['inlier_percent'] == oo['inlier_percent'] and np.array_equal(dd['inlier_idx'], oo['inlier_idx']))
+        if same and oo['best_try'] >= 0:
+            same = mc.parallel(dd['essential'], oo['essential']) >= 1 - 1e-9 and min(np.abs(dd['camera'] - oo['camera']).max(), np.abs(dd['camera'] + oo['camera']).max()) < 1e-8  # -P is the same camera
+        if not same:
+            raise SystemExit("RANSAC FIT MISMATCH case=%d npt=%d outliers=%g tries=%d %r: device (try %d root %d, %d inliers) "
+                             "oracle (try %d root %d, %d inliers)" % (n, npt, frac, tries, kw, dd['best_try'], dd['best_root'],
+                                                                      len(dd['inlier_idx']), oo['best_try'], oo['best_root'],
+                                                                      len(oo['inlier_idx'])))
+        n += 1
+        if only_case is not None:
+            break
+    return n
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0, help="budget per path")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma list of l1k2,cascade,dlt,ratio,score,normalize")
+    ap.add_argument("--only", default="", help="comma list of l1k2,cascade,dlt,ratio,score,normalize,seven_point,ransac_fit")
     ap.add_argument("--case", type=int, default=None, help="re-run one case number of the --only path")
     a = ap.parse_args()
     want = set(filter(None, a.only.split(",")))
     for name, fn in (("l1k2", fuzz_l1k2), ("cascade", fuzz_cascade), ("dlt", fuzz_dlt), ("ratio", fuzz_ratio),
-                     ("score", fuzz_score), ("normalize", fuzz_normalize)):
+                     ("score", fuzz_score), ("normalize", fuzz_normalize), ("seven_point", fuzz_seven_point),
+                     ("ransac_fit", fuzz_ransac_fit)):
         if want and name not in want:
             continue
         cases = fn(a.seed, a.seconds, a.case)
-        print("%s: %d random cases bit-identical to the oracle" % (name, cases), flush=True)
+        print("%s: %d random cases %s the oracle" % (name, cases, "agree with" if name in ("seven_point", "ransac_fit")
+                                                       else "bit-identical to"), flush=True)

@@ -110,7 +110,9 @@ def _same_model(dev, o, exact_inliers=True):
         return
     assert mc.parallel(dev['essential'], o['essential']) >= 1 - 1e-9
     assert np.allclose(dev['essential'], o['essential'], rtol=1e-8, atol=1e-10 * np.abs(o['essential']).max())
-    assert np.allclose(dev['camera'], o['camera'], rtol=0, atol=1e-8)
+    # up to the sign of the whole matrix: E has two equal singular values, so the order Essential2Cameras'
+    # SVD gives them (and with it the signs of t and R) hangs on the last bit of F; -P is the same camera
+    assert min(np.abs(dev['camera'] - o['camera']).max(), np.abs(dev['camera'] + o['camera']).max()) < 1e-8
 
 
 @pytest.mark.parametrize("npt,outliers,noise", [(200, 0.25, 0.0), (777, 0.3, 2e-4), (64, 0.1, 0.0), (2500, 0.35, 1e-4)])
