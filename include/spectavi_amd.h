@@ -290,6 +290,16 @@ int spv_ransac_fit_samples(const double *x0, const double *x1, int npt, double r
                            int find_best_even_in_failure, double singular_value_ratio_allowed, int32_t *success,
                            double *essential, double *camera, double *inlier_percent, int32_t *inlier_idx,
                            int32_t *n_inliers, int32_t *best_try, int32_t *best_root, int32_t *tries_run);
+/* The correspondences already in HBM (d_x0, d_x1 double[npt,3] on the caller's current device, e.g.
+ * what spv_gather_match_coords_device left there): samples (host int32[maximum_tries,7]) or, if
+ * NULL, the seed choose the subsets; the small results come back to host memory.  Synchronises
+ * `stream` after every batch of tries (the loop stops at the first success). */
+int spv_ransac_fit_device(const double *d_x0, const double *d_x1, int npt, double required_percent_inliers,
+                          double reprojection_error_allowed, int maximum_tries, int find_best_even_in_failure,
+                          double singular_value_ratio_allowed, unsigned long long seed, const int32_t *samples,
+                          int32_t *success, double *essential, double *camera, double *inlier_percent,
+                          int32_t *inlier_idx, int32_t *n_inliers, int32_t *best_try, int32_t *best_root,
+                          int32_t *tries_run, void *stream);
 
 int spv_dlt_triangulate(const double *P0, const double *P1, int npt, const double *x,
                         const double *xp, double *dst);

@@ -962,25 +962,30 @@ int check_fit_args(const double *x0, const double *x1, int npt, int max_tries) {
 }
 
 // samples != NULL: the 7-subsets of the tries, int32[max_tries,7]; otherwise drawn from `seed`.
+// inputs_on_device: x0 / x1 are device pointers (the caller's current device) and `st` the caller's stream.
 int host_ransac_fit(const double *x0, const double *x1, int npt, double required_percent, double max_error,
                     int max_tries, int find_best, double ratio_allowed, const int32_t *samples, uint64_t seed,
                     int32_t *success, double *essential, double *camera, double *inlier_percent,
                     int32_t *inlier_idx, int32_t *n_inliers, int32_t *best_try, int32_t *best_root,
-                    int32_t *tries_run) {
+                    int32_t *tries_run, bool inputs_on_device = false, hipStream_t st = hipStreamPerThread) {
   SPV_TRY(check_fit_args(x0, x1, npt, max_tries));
   if (!success || !essential || !camera || !inlier_percent || !inlier_idx || !n_inliers)
     return set_error(SPV_ERR_INVALID, "null pointer");
-  SPV_TRY(ensure_device());
+  if (!inputs_on_device) SPV_TRY(ensure_device());
   const int batch = std::min(ransac_fit_batch_limit(npt), std::max(max_tries, 1));
   const size_t wsb = ransac_fit_workspace_bytes(batch, npt);
   const size_t ib = (size_t)npt * 3 * sizeof(double);
   DevBuf dx, dxp, ws;
-  SPV_TRY(dx.alloc(ib));
-  SPV_TRY(dxp.alloc(ib));
   SPV_TRY(ws.alloc(wsb));
-  hipStream_t st = hipStreamPerThread;
-  SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x0, ib, hipMemcpyHostToDevice, st));
-  SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, x1, ib, hipMemcpyHostToDevice, st));
+  const double *d_x0 = x0, *d_x1 = x1;
+  if (!inputs_on_device) {
+    SPV_TRY(dx.alloc(ib));
+    SPV_TRY(dxp.alloc(ib));
+    SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x0, ib, hipMemcpyHostToDevice, st));
+    SPV_HIP_CHECK(hipMemcpyAsync(dxp.p, x1, ib, hipMemcpyHostToDevice, st));
+    d_x0 = dx.as<double>();
+    d_x1 = dxp.as<double>();
+  }
   std::mt19937 gen(samples ? 0u : ransac_seed(seed));
   auto next = [&](int first, int n, int *dst) {
     if (samples) {
@@ -991,9 +996,12 @@ int host_ransac_fit(const double *x0, const double *x1, int npt, double required
   };
   std::vector<unsigned char> mask((size_t)npt, 0);
   int ok = 0, ninl = 0, bt = -1, br = -1, ran = 0;
-  SPV_TRY(ransac_fit_run(dx.as<double>(), dxp.as<double>(), npt, required_percent, max_error, max_tries, find_best,
-                         ratio_allowed, next, &ok, essential, camera, &ninl, mask.data(), &bt, &br, &ran, ws.p, wsb,
-                         batch, st));
+  const int rc = ransac_fit_run(d_x0, d_x1, npt, required_percent, max_error, max_tries, find_best, ratio_allowed, next,
+                                &ok, essential, camera, &ninl, mask.data(), &bt, &br, &ran, ws.p, wsb, batch, st);
+  // the workspace goes back to the pool below: nothing may still be running on a caller's stream
+  // (DevBuf's destructor only drains this thread's own stream)
+  if (rc != SPV_OK && st != hipStreamPerThread) (void)hipStreamSynchronize(st);
+  SPV_TRY(rc);
   *success = ok;
   *inlier_percent = (double)ninl / (double)npt;
   int n = 0;
@@ -1601,6 +1609,20 @@ int spv_ransac_fit(const double *x0, const double *x1, int npt, double required_
     return host_ransac_fit(x0, x1, npt, required_percent_inliers, reprojection_error_allowed, maximum_tries,
                            find_best_even_in_failure, singular_value_ratio_allowed, nullptr, seed, success, essential,
                            camera, inlier_percent, inlier_idx, n_inliers, best_try, best_root, tries_run);
+  });
+}
+int spv_ransac_fit_device(const double *d_x0, const double *d_x1, int npt, double required_percent_inliers,
+                          double reprojection_error_allowed, int maximum_tries, int find_best_even_in_failure,
+                          double singular_value_ratio_allowed, unsigned long long seed, const int32_t *samples,
+                          int32_t *success, double *essential, double *camera, double *inlier_percent,
+                          int32_t *inlier_idx, int32_t *n_inliers, int32_t *best_try, int32_t *best_root,
+                          int32_t *tries_run, void *stream) {
+  clear_error();
+  return guard([&] {
+    return host_ransac_fit(d_x0, d_x1, npt, required_percent_inliers, reprojection_error_allowed, maximum_tries,
+                           find_best_even_in_failure, singular_value_ratio_allowed, samples, seed, success, essential,
+                           camera, inlier_percent, inlier_idx, n_inliers, best_try, best_root, tries_run, true,
+                           static_cast<hipStream_t>(stream));
   });
 }
 int spv_ransac_fit_samples(const double *x0, const double *x1, int npt, double required_percent_inliers,

@@ -294,3 +294,67 @@ def ransac_process_candidates(Fs, x0, x1, singular_value_ratio_allowed=3e-2, req
     if want_mask:
         out["inlier_mask"] = mask
     return out
+
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+clib.spv_ransac_fit_device.restype = ct.c_int
+clib.spv_ransac_fit_device.argtypes = [_vp, _vp, ct.c_int, ct.c_double, ct.c_double, ct.c_int, ct.c_int, ct.c_double,
+                                       ct.c_ulonglong, _vp, ct.POINTER(ct.c_int32), _f64p, _f64p,
+                                       ct.POINTER(ct.c_double), _i32p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32),
+                                       ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), _vp]
+
+
+def ransac_fit(x0, x1, required_percent_inliers=.9, reprojection_error_allowed=.5, maximum_tries=500,
+               find_best_even_in_failure=True, singular_value_ratio_allowed=3e-2, seed=0, samples=None):
+    """`mvg.ransac_fit` with the correspondences resident in HBM (reference RansacFitter::fit_essential,
+    src/RansacFitter.h:152-272): x0, x1 CUDA float64 [npt,3] (e.g. the output of `match_coordinates` after
+    calibration).  The small results come back as numpy: the `mvg.ransac_fit` dict.  Synchronises the
+    current stream once per batch of tries."""
+    _need(x0, torch.float64, "x0")
+    _need(x1, torch.float64, "x1")
+    assert x0.shape == x1.shape and x0.dim() == 2 and x0.shape[1] == 3
+    npt = x0.shape[0]
+    if npt < 10:
+        raise ValueError('Supplied less than 10 point matches, unsupported.')
+    if samples is not None:
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        if not (samples.ndim == 2 and samples.shape[1] == 7):
+            raise TypeError('samples must be [ntries,7].')
+        maximum_tries = samples.shape[0]
+    ok, n, bt, br, ran = ct.c_int32(0), ct.c_int32(0), ct.c_int32(-1), ct.c_int32(-1), ct.c_int32(0)
+    pct = ct.c_double(0.0)
+    F, P, idx = np.zeros(9), np.zeros(12), np.zeros(npt, np.int32)
+    with _on_device_of(x0, x1) as stream:
+        check(clib.spv_ransac_fit_device(
+            x0.data_ptr(), x1.data_ptr(), npt, float(required_percent_inliers), float(reprojection_error_allowed),
+            int(maximum_tries), int(bool(find_best_even_in_failure)), float(singular_value_ratio_allowed), int(seed),
+            samples.ctypes.data if samples is not None else None, ct.byref(ok), F, P, ct.byref(pct), idx, ct.byref(n),
+            ct.byref(bt), ct.byref(br), ct.byref(ran), stream))
+    found = bt.value >= 0
+    return {'success': bool(ok.value), 'essential': F.reshape(3, 3) if found else None,
+            'camera': P.reshape(3, 4) if found else None, 'inlier_percent': float(pct.value),
+            'inlier_idx': idx[:n.value].copy(), 'best_try': bt.value, 'best_root': br.value, 'tries_run': ran.value}
+
+
+clib.spv_normalize_workspace_bytes.restype = ct.c_size_t
+clib.spv_normalize_workspace_bytes.argtypes = [ct.c_int]
+clib.spv_normalize_device.restype = ct.c_int
+clib.spv_normalize_device.argtypes = [_vp, ct.c_int, ct.c_int, _vp, _vp, _vp, ct.c_size_t, _vp]
+
+
+def normalize(x, want_float=True, want_ubyte=False, workspace=None):
+    """`normalize_to_ubyte_and_multiple_16_dim` (reference spectavi/feature.py:384-407) on a CUDA float32
+    [rows, dim] table, bit-identical to the numpy function: returns the float32 [rows, dim16] table
+    and / or its `(out + 128).astype('uint8')` image (what `l1k2` takes).  Asynchronous."""
+    _need(x, torch.float32, "x")
+    rows, dim = x.shape
+    dim16 = (dim + 15) // 16 * 16
+    out = torch.empty((rows, dim16), dtype=torch.float32, device=x.device) if want_float else None
+    u8 = torch.empty((rows, dim16), dtype=torch.uint8, device=x.device) if want_ubyte else None
+    with _on_device_of(x) as stream:
+        ws = (workspace or _default_ws).get(clib.spv_normalize_workspace_bytes(dim), x.device)
+        check(clib.spv_normalize_device(x.data_ptr(), rows, dim, out.data_ptr() if want_float else None,
+                                        u8.data_ptr() if want_ubyte else None, ws.data_ptr(), ws.numel(), stream))
+    if want_float and want_ubyte:
+        return out, u8
+    return out if want_float else u8
