@@ -12,7 +12,7 @@ default, since extracting them is not part of this library -- in two forms:
   * `device_pipeline`: the same steps with every intermediate resident in HBM (`spectavi_amd.device`),
     only the RANSAC result and the triangulated points come back.
 
-    python examples/ex01_essential_estimation.py [--features 20000] [--matching-method cascading-hash]
+    python examples/essential_from_sift_tables.py [--features 20000] [--matching-method cascading-hash]
 """
 import argparse
 import os

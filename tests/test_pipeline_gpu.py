@@ -6,7 +6,7 @@ cascade hash, ratio test, SIFT-table split, match coordinates, RANSAC fit, DLT."
 import numpy as np
 import pytest
 
-from examples import ex01_essential_estimation as ex
+from examples import essential_from_sift_tables as ex
 
 pytestmark = pytest.mark.gpu
 
