@@ -375,6 +375,10 @@ int spv_gather_match_coords_device(const float *d_geom_x, const float *d_geom_y,
  * uint8(out + 128)[rows,dim16] (either may be NULL, not both). */
 int spv_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *out_u8);
 size_t spv_normalize_workspace_bytes(int dim);
+/* A larger workspace (it grows with rows) with which spv_normalize_device computes the column sums
+ * of a table of 65536 rows or more by folding 1024-row chunks instead of walking every row: the same
+ * bits, 1.5x (full SIFT tables) to 3.7x (integer-valued tables) faster at a million rows.  With only spv_normalize_workspace_bytes(dim) it walks. */
+size_t spv_normalize_workspace_bytes_rows(int rows, int dim);
 int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, uint8_t *d_out_u8,
                          void *d_ws, size_t ws_bytes, void *stream);
 

@@ -13,6 +13,8 @@
 
 #include "common.h"
 
+#include <cstdlib>
+
 namespace spv {
 namespace {
 
@@ -113,8 +115,10 @@ constexpr int kStatRows = 512;  // rows per LDS tile (double buffered: 2 x 32 KB
 // stats[0][c] = mean, stats[1][c] = max(max - mean, -(min - mean)).
 constexpr int kStatThreads = 320;
 __global__ __launch_bounds__(kStatThreads) void column_stats_kernel(const float *__restrict__ x, int rows,
-                                                                    int dim, float *__restrict__ stats) {
+                                                                    int dim, float *__restrict__ stats,
+                                                                    const int *__restrict__ only_blocks) {
   __shared__ float tile[2][kStatRows * kStatCols];  // [row][column]
+  if (only_blocks && !only_blocks[blockIdx.x]) return;  // this block's sums come from the folded chain
   constexpr int NL = kStatRows * kStatCols / 256;   // 32 floats per loader lane per tile
   const int t = threadIdx.x;
   const bool loader = t >= 64;
@@ -202,6 +206,442 @@ __global__ __launch_bounds__(kStatThreads) void column_stats_kernel(const float 
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The same column sums -- the same bits -- without walking every column's 10^6 dependent adds
+// (9.25 cycles each, tools/exp/dep_add.hip: 3.85 ms per million rows however many CUs there are).
+//
+// fl(S + x) rounds the exact sum E to a multiple of Q = 2^(floor(log2|E|) - 23), ties to even.
+// While S and E stay inside ONE binade, Q is constant and S = T Q with an integer T, so a step is
+//     x = a Q + b  (a = floor(x / Q), 0 <= b < Q),   T' = T + a + c,
+//     c = 0 if b < Q/2,  1 if b > Q/2,  and on a tie whatever makes T' even, i.e. parity(T + a):
+// the only thing a step needs to know about T is its PARITY.  A run of rows is therefore a function
+// parity -> (sum of a + c, parity after), two table entries, and such functions compose
+// associatively: rows can be folded in any grouping as long as the order is kept.  (All integer
+// arithmetic on the float's mantissa; nothing here is approximate.)
+//
+//   colsum_stats_kernel      per (1024-row chunk, column): double sum, min / max of its prefix sums,
+//                            max, min, all-finite flag                                  [parallel]
+//   colsum_plan_kernel       per column, over the chunks: the binade each chunk is EXPECTED to
+//                            stay in (from the double prefix), or "no guess"            [1 lane / column]
+//   colsum_fold_kernel       per (chunk, column) with a guess: the two-entry function   [parallel]
+//   colsum_chain_kernel      per column, over the chunks, carrying the TRUE float S: where S is in
+//                            the guessed binade and S + (prefix min / max -+ a margin for the
+//                            rounding so far) cannot leave it, apply the function: one table
+//                            look-up for 1024 rows, all in integers on S's significand; anywhere
+//                            else -- binade crossings, S = 0, cancellation, inf / nan -- add the
+//                            chunk's rows one by one (wave-cooperative loads, runs of such chunks
+//                            double buffered, the batch handed to the chain through LDS)  [1 wave / column]
+// A guess is only ever a guess: it is the chain kernel's check against the true S that licenses
+// the shortcut.  Columns whose chunks would mostly fall back (symmetric mixed-sign data, an early
+// nan) are left to column_stats_kernel, which walks them at the dependent-add rate.
+// ---------------------------------------------------------------------------------
+constexpr int kFoldChunk = 1024;   // rows per chunk
+constexpr int kFoldTile = 256;     // rows staged per step
+constexpr int kFoldCols = 16;      // columns per workgroup: one 64-byte sector of every row
+constexpr int kFoldThreads = 256;
+constexpr int kFoldStride = kFoldCols + 1;
+constexpr int kNoGuess = -1000;
+
+struct FoldBufs {
+  // per (column, chunk) records, [dim][chunks]: a column's chunks are contiguous, so the kernels
+  // that walk a column's chunks in order fetch 64 of them with one coalesced load per field
+  double *csum, *cpmin, *cpmax;
+  float *cvmax, *cvmin;
+  int *cfinite;
+  int *eguess;
+  int *d0, *d1;
+  int *tlo, *thi;                // the chunk keeps T + tlo .. T + thi inside the binade or is walked
+  int *qq;                       // bit 0 = parity after from 0, bit 1 = from 1; -1 = unusable
+  int nchunks;
+  float *colvmax, *colvmin;      // [dim]
+  int *blockserial;              // [column blocks]: 1 = column_stats_kernel takes this block
+};
+
+// Stage rows [row0, row0 + 256) x 16 columns of x into LDS (coalesced 64-byte pieces), +0 outside.
+__device__ __forceinline__ void fold_stage(const float *__restrict__ x, int rows, int dim, long long row0, int c0,
+                                           float *tile) {
+  const int t = threadIdx.x, col = t & 15, rs = t >> 4;
+  const bool colok = c0 + col < dim;
+#pragma unroll
+  for (int i = 0; i < kFoldTile / 16; ++i) {
+    const long long r = row0 + rs + 16 * i;
+    tile[(rs + 16 * i) * kFoldStride + col] = (colok && r < rows) ? x[(size_t)r * dim + c0 + col] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(kFoldThreads) void colsum_stats_kernel(const float *__restrict__ x, int rows, int dim,
+                                                                    FoldBufs fb) {
+  __shared__ float tile[kFoldTile * kFoldStride];
+  __shared__ double r_sum[16][16], r_min[16][16], r_max[16][16];
+  __shared__ float r_vmax[16][16], r_vmin[16][16];
+  __shared__ int r_fin[16][16];
+  const int t = threadIdx.x, col = t & 15, rb = t >> 4;
+  // column block fastest: the workgroups that share a row's 128-byte lines run side by side
+  const int chunk = blockIdx.y, c0 = blockIdx.x * kFoldCols;
+  double run_sum = 0.0, run_min = 0.0, run_max = 0.0;
+  float run_vmax = -__builtin_inff(), run_vmin = __builtin_inff();
+  int run_fin = 1;
+  for (int tl = 0; tl < kFoldChunk / kFoldTile; ++tl) {
+    const long long row0 = (long long)chunk * kFoldChunk + (long long)tl * kFoldTile;
+    if (row0 >= rows) break;  // uniform
+    fold_stage(x, rows, dim, row0, c0, tile);
+    __syncthreads();
+    double ls = 0.0, lmin = 0.0, lmax = 0.0;
+    float vmx = -__builtin_inff(), vmn = __builtin_inff();
+    int fin = 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (row0 + rb * 16 + r < rows) {
+        const float v = tile[(rb * 16 + r) * kFoldStride + col];
+        ls += (double)v;
+        lmin = fmin(lmin, ls);
+        lmax = fmax(lmax, ls);
+        vmx = fmaxf(vmx, v);
+        vmn = fminf(vmn, v);
+        fin &= (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u;
+      }
+    }
+    r_sum[rb][col] = ls;
+    r_min[rb][col] = lmin;
+    r_max[rb][col] = lmax;
+    r_vmax[rb][col] = vmx;
+    r_vmin[rb][col] = vmn;
+    r_fin[rb][col] = fin;
+    __syncthreads();
+    if (t < 16) {
+      for (int k = 0; k < 16; ++k) {
+        run_min = fmin(run_min, run_sum + r_min[k][t]);
+        run_max = fmax(run_max, run_sum + r_max[k][t]);
+        run_sum += r_sum[k][t];
+        run_vmax = fmaxf(run_vmax, r_vmax[k][t]);
+        run_vmin = fminf(run_vmin, r_vmin[k][t]);
+        run_fin &= r_fin[k][t];
+      }
+    }
+    __syncthreads();
+  }
+  if (t < 16 && c0 + t < dim) {
+    const size_t o = (size_t)(c0 + t) * fb.nchunks + chunk;
+    fb.csum[o] = run_sum;
+    fb.cpmin[o] = run_min;
+    fb.cpmax[o] = run_max;
+    fb.cvmax[o] = run_vmax;
+    fb.cvmin[o] = run_vmin;
+    fb.cfinite[o] = run_fin;
+  }
+}
+
+// floor(log2 |v|) of a finite nonzero double
+__device__ __forceinline__ int dexp(double v) { return (int)((__double_as_longlong(v) >> 52) & 0x7FF) - 1023; }
+
+__device__ __forceinline__ bool same_binade(double lo, double hi, int &e) {
+  if (!(lo == lo) || !(hi == hi) || lo == 0.0 || hi == 0.0 || (lo > 0.0) != (hi > 0.0)) return false;
+  const int el = dexp(lo), eh = dexp(hi);
+  if (el != eh || el < -100 || el > 100) return false;  // (well inside the float32 normal range)
+  e = el;
+  return true;
+}
+
+// One wave per column, 64 chunks per step: the prefix P of the chunk sums is only a guess (any
+// summation order will do), so it is a wave scan; so are "has an inf / nan entered the sum" and the
+// count of chunks without a guess.
+__global__ __launch_bounds__(64) void colsum_plan_kernel(int nchunks, int dim, FoldBufs fb, int *__restrict__ colserial) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double carry = 0.0;
+  int poisoned = 0, fallbacks = 0;
+  float vmx = -__builtin_inff(), vmn = __builtin_inff();
+  for (int j0 = 0; j0 < nchunks; j0 += 64) {
+    const int j = j0 + lane;
+    const bool live = j < nchunks;
+    const size_t o = (size_t)c * nchunks + (live ? j : nchunks - 1);
+    const double s = live ? fb.csum[o] : 0.0;
+    const int bad = live ? !fb.cfinite[o] : 0;
+    // inclusive scans over the 64 chunks of this step
+    double incl = s;
+    int pbad = bad;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double up = __shfl_up(incl, d, 64);
+      const int ub = __shfl_up(pbad, d, 64);
+      if (lane >= d) {
+        incl += up;
+        pbad |= ub;
+      }
+    }
+    const double P = carry + incl - s;  // exclusive
+    int e = kNoGuess;
+    if (live && !(poisoned | pbad)) {
+      int ee;
+      if (same_binade(P + fb.cpmin[o], P + fb.cpmax[o], ee)) e = ee;
+    }
+    if (live) {
+      fb.eguess[o] = e;
+      vmx = fmaxf(vmx, fb.cvmax[o]);
+      vmn = fminf(vmn, fb.cvmin[o]);
+    }
+    fallbacks += __popcll(__ballot(live && e == kNoGuess));
+    carry += __shfl(incl, 63, 64);
+    poisoned |= __shfl(pbad, 63, 64);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    vmx = fmaxf(vmx, __shfl_down(vmx, d, 64));
+    vmn = fminf(vmn, __shfl_down(vmn, d, 64));
+  }
+  if (lane == 0) {
+    fb.colvmax[c] = vmx;
+    fb.colvmin[c] = vmn;
+    colserial[c] = fallbacks * 10 > nchunks * 6;
+  }
+}
+
+// a 16-column block goes to column_stats_kernel when any of its columns would mostly be walked
+__global__ void colsum_blockmode_kernel(int dim, const int *__restrict__ colserial, int *__restrict__ blockserial) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * kFoldCols >= dim) return;
+  int any = 0;
+  for (int c = b * kFoldCols; c < min(dim, (b + 1) * kFoldCols); ++c) any |= colserial[c];
+  blockserial[b] = any;
+}
+
+// one row relative to the quantum 2^kq: a = floor(x / Q) and how b = x - a Q compares with Q / 2
+// (-1 below or b = 0, 0 tie, +1 above); false if a does not fit (the row is far too big for this
+// binade: the chunk cannot stay in it, and the chain kernel's bounds will say so as well)
+__device__ __forceinline__ bool fold_elem(uint32_t bits, int kq, int &a, int &bc) {
+  const uint32_t ef = (bits >> 23) & 0xFFu, man = bits & 0x7FFFFFu;
+  const bool neg = (bits >> 31) != 0;
+  a = 0;
+  bc = -1;
+  if (ef == 0 && man == 0) return true;
+  const uint32_t m = man | (ef ? 0x800000u : 0u);
+  const int exu = (int)(ef ? ef : 1u) - 127;
+  const int sh = kq - (exu - 23);
+  if (sh <= 0) {
+    if (-sh > 6) return false;
+    const int av = (int)(m << (-sh));
+    a = neg ? -av : av;
+    return true;
+  }
+  if (sh >= 26) {  // |x| < Q / 4
+    if (neg) {
+      a = -1;
+      bc = 1;
+    }
+    return true;
+  }
+  const uint32_t apos = m >> sh, rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+  uint32_t b;
+  if (!neg) {
+    a = (int)apos;
+    b = rem;
+  } else if (rem == 0) {
+    a = -(int)apos;
+    b = 0;
+  } else {
+    a = -(int)apos - 1;
+    b = (1u << sh) - rem;
+  }
+  bc = b == 0 ? -1 : (b < half ? -1 : (b == half ? 0 : 1));
+  return true;
+}
+
+__global__ __launch_bounds__(kFoldThreads) void colsum_fold_kernel(const float *__restrict__ x, int rows, int dim,
+                                                                   FoldBufs fb) {
+  __shared__ float tile[kFoldTile * kFoldStride];
+  __shared__ int r_d0[16][16], r_d1[16][16], r_q[16][16];
+  __shared__ int s_e[16];
+  __shared__ int s_any;
+  const int t = threadIdx.x, col = t & 15, rb = t >> 4;
+  const int chunk = blockIdx.y, c0 = blockIdx.x * kFoldCols;
+  if (fb.blockserial[blockIdx.x]) return;  // uniform
+  if (t == 0) s_any = 0;
+  __syncthreads();
+  if (t < 16) {
+    const int e = c0 + t < dim ? fb.eguess[(size_t)(c0 + t) * fb.nchunks + chunk] : kNoGuess;
+    s_e[t] = e;
+    if (e != kNoGuess) atomicOr(&s_any, 1);
+  }
+  __syncthreads();
+  if (!s_any) return;  // uniform: nothing to fold in this (chunk, column block)
+  const int e = s_e[col];
+  const int kq = e - 23;
+  long long run_d0 = 0, run_d1 = 0;
+  int run_q0 = 0, run_q1 = 1, run_ok = 1;
+  for (int tl = 0; tl < kFoldChunk / kFoldTile; ++tl) {
+    const long long row0 = (long long)chunk * kFoldChunk + (long long)tl * kFoldTile;
+    if (row0 >= rows) break;  // uniform
+    fold_stage(x, rows, dim, row0, c0, tile);
+    __syncthreads();
+    int d0 = 0, d1 = 0, q0 = 0, q1 = 1, ok = 1;
+    if (e != kNoGuess) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (row0 + rb * 16 + r < rows) {
+          int a, bc;
+          ok &= fold_elem(__float_as_uint(tile[(rb * 16 + r) * kFoldStride + col]), kq, a, bc) ? 1 : 0;
+          const int par0 = q0 ^ (a & 1), par1 = q1 ^ (a & 1);
+          const int c0_ = bc < 0 ? 0 : (bc > 0 ? 1 : par0), c1_ = bc < 0 ? 0 : (bc > 0 ? 1 : par1);
+          d0 += a + c0_;
+          d1 += a + c1_;
+          q0 = par0 ^ c0_;
+          q1 = par1 ^ c1_;
+        }
+      }
+    }
+    r_d0[rb][col] = d0;
+    r_d1[rb][col] = d1;
+    r_q[rb][col] = q0 | (q1 << 1) | (ok ? 0 : 4);
+    __syncthreads();
+    if (t < 16) {
+      for (int k = 0; k < 16; ++k) {
+        const int q = r_q[k][t];
+        const long long g0 = r_d0[k][t], g1 = r_d1[k][t];
+        const int gq0 = q & 1, gq1 = (q >> 1) & 1;
+        run_ok &= (q & 4) ? 0 : 1;
+        // (running) then (this run of 16 rows)
+        run_d0 += run_q0 ? g1 : g0;
+        run_d1 += run_q1 ? g1 : g0;
+        run_q0 = run_q0 ? gq1 : gq0;
+        run_q1 = run_q1 ? gq1 : gq0;
+      }
+    }
+    __syncthreads();
+  }
+  if (t < 16 && c0 + t < dim && s_e[t] != kNoGuess) {
+    const size_t o = (size_t)(c0 + t) * fb.nchunks + chunk;
+    bool fits = run_ok && run_d0 > -(1ll << 26) && run_d0 < (1ll << 26) && run_d1 > -(1ll << 26) && run_d1 < (1ll << 26);
+    // how far, in units of Q, the running sum can move away from its value at the chunk's start:
+    // the exact prefix range, widened by the rounding the chain can accumulate (<= Q / 2 per row)
+    const double Q = __builtin_ldexp(1.0, s_e[t] - 23);
+    const double lo = __builtin_floor((fb.cpmin[o]) / Q) - (double)kFoldChunk;
+    const double hi = __builtin_ceil((fb.cpmax[o]) / Q) + (double)kFoldChunk;
+    fits = fits && lo > -33554432.0 && hi < 33554432.0;  // 2^25: nothing that could stay in the binade is lost
+    fb.d0[o] = (int)run_d0;
+    fb.d1[o] = (int)run_d1;
+    fb.tlo[o] = fits ? (int)lo : 0;
+    fb.thi[o] = fits ? (int)hi : 0;
+    fb.qq[o] = fits ? (run_q0 | (run_q1 << 1)) : -1;
+  }
+}
+
+// One wave per column.  Every lane carries the same S.  The records of 64 chunks are fetched at
+// once (one per lane, coalesced) and handed to the sequential part with v_readlane, so the chain
+// never waits for memory between two chunks it can fold; lanes only differ when a chunk is walked
+// (each loads its own rows, v_readlane feeds them to the chain in row order).
+__device__ __forceinline__ int rl_i(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+
+// Rows [r0, r0 + n) of column c added to S one by one, in order: every lane loads its own row of a
+// 64-row batch and the batch is handed to the chain through LDS.  Groups of 1024 rows are double buffered, so
+// only the first group of a run of walked chunks waits for memory.
+__device__ __forceinline__ void walk_rows(const float *__restrict__ x, int dim, int c, long long r0, long long n,
+                                          int lane, float *wbuf, float &S) {
+  constexpr int NB = kFoldChunk / 64;
+  float va[NB], vb[NB];
+  const long long end = r0 + n;
+  auto load = [&](float (&v)[NB], long long base) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const long long r = base + 64 * b + lane;
+      v[b] = r < end ? x[(size_t)r * dim + c] : 0.f;
+    }
+  };
+  // a batch goes through a 256-byte LDS slot (two slots, alternating): every lane reads the 64 values
+  // back with 16-byte broadcast reads, so the chain's operands are plain VGPRs.  (v_readlane feeding
+  // the adds through one SGPR costs ~17 cycles per row instead of the 9.25 of the dependent add: each
+  // readlane has to wait for the add before it to release the register, and the add after it for
+  // the readlane's hazard slots.)
+  auto chain = [&](const float (&v)[NB], long long base) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const long long left = end - (base + 64 * b);
+      float *slot = wbuf + 64 * (b & 1);
+      slot[lane] = v[b];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (left >= 64) {
+        float4 r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r[k] = reinterpret_cast<const float4 *>(slot)[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          S += r[k].x;
+          S += r[k].y;
+          S += r[k].z;
+          S += r[k].w;
+        }
+      } else {
+        for (int k = 0; k < left; ++k) S += slot[k];
+      }
+    }
+  };
+  load(va, r0);
+  for (long long g = r0; g < end; g += 2 * kFoldChunk) {
+    const bool more1 = g + kFoldChunk < end;
+    if (more1) load(vb, g + kFoldChunk);
+    chain(va, g);
+    if (more1) {
+      if (g + 2 * kFoldChunk < end) load(va, g + 2 * kFoldChunk);
+      chain(vb, g + kFoldChunk);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void colsum_chain_kernel(const float *__restrict__ x, int rows, int dim, int nchunks,
+                                                          FoldBufs fb, float *__restrict__ stats) {
+  __shared__ __attribute__((aligned(16))) float wbuf[128];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (fb.blockserial[c / kFoldCols]) return;
+  float S = 0.f;
+  for (int j0 = 0; j0 < nchunks; j0 += 64) {
+    const int jl = min(j0 + lane, nchunks - 1);
+    const size_t o = (size_t)c * nchunks + jl;
+    const int ev = fb.eguess[o], qv = fb.qq[o], d0v = fb.d0[o], d1v = fb.d1[o];
+    const int lov = fb.tlo[o], hiv = fb.thi[o];
+    const int nk = min(64, nchunks - j0);
+    // chunks without a guess are walked for certain: consecutive ones as ONE run
+    const unsigned long long noguess = __ballot(lane < nk && ev == kNoGuess);
+    for (int k = 0; k < nk;) {
+      const long long r0 = (long long)(j0 + k) * kFoldChunk;
+      if ((noguess >> k) & 1ull) {
+        const unsigned long long rest = ~(noguess >> k);
+        const int run = min(rest ? __builtin_ctzll(rest) : 64, nk - k);
+        walk_rows(x, dim, c, r0, min((long long)run * kFoldChunk, (long long)rows - r0), lane, wbuf, S);
+        k += run;
+        continue;
+      }
+      const int e = rl_i(ev, k);
+      bool fast = false;
+      const int q = rl_i(qv, k);
+      // S is the same in every lane: telling the compiler so keeps this whole test on the scalar unit
+      const uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(S));
+      const int es = (int)((sb >> 23) & 0xFFu) - 127;  // S = 0 / subnormal / inf / nan never match a guess
+      if (q >= 0 && es == e) {
+        // S = T Q with Q = 2^(e - 23): T is S's 24-bit significand with its sign
+        const int mag = (int)((sb & 0x7FFFFFu) | 0x800000u);
+        const bool neg = (sb >> 31) != 0;
+        int T = neg ? -mag : mag;
+        // the whole chunk inside the binade: 2^23 <= |T + t| < 2^24 for every t in [tlo, thi]
+        const int lo = T + rl_i(lov, k), hi = T + rl_i(hiv, k);
+        const bool inside = neg ? (lo > -(1 << 24) && hi <= -(1 << 23)) : (lo >= (1 << 23) && hi < (1 << 24));
+        if (inside) {
+          T += (T & 1) ? rl_i(d1v, k) : rl_i(d0v, k);
+          const uint32_t am = (uint32_t)(T < 0 ? -T : T);  // in [2^23, 2^24) by the bounds
+          S = __uint_as_float((sb & 0x80000000u) | ((uint32_t)(e + 127) << 23) | (am & 0x7FFFFFu));
+          fast = true;
+        }
+      }
+      if (!fast) walk_rows(x, dim, c, r0, min((long long)kFoldChunk, (long long)rows - r0), lane, wbuf, S);
+      ++k;
+    }
+  }
+  if (lane == 0) {
+    const float mean = S / (float)rows;
+    stats[c] = mean;
+    stats[dim + c] = fmaxf(fb.colvmax[c] - mean, -(fb.colvmin[c] - mean));
+  }
+}
+
 __global__ __launch_bounds__(256) void normalize_apply_kernel(const float *__restrict__ x, int rows,
                                                               int dim, int dim16,
                                                               const float *__restrict__ stats,
@@ -227,6 +667,20 @@ __global__ __launch_bounds__(256) void normalize_apply_kernel(const float *__res
 
 size_t normalize_workspace_bytes(int dim) { return round_up((size_t)2 * std::max(dim, 1) * sizeof(float), 256); }
 
+static int fold_chunks(int rows) { return (rows + kFoldChunk - 1) / kFoldChunk; }
+
+// workspace that lets normalize_run fold the column sums (tables of at least kFoldMinRows rows)
+constexpr int kFoldMinRows = 64 * kFoldChunk;  // below this the launches and the always-walked first chunks (the sum
+                                               // doubles through a binade per chunk at first) cost more than walking
+size_t normalize_workspace_bytes_rows(int rows, int dim) {
+  size_t b = normalize_workspace_bytes(dim);
+  if (rows < kFoldMinRows) return b;
+  const size_t n = (size_t)fold_chunks(rows) * std::max(dim, 1);
+  b += 3 * round_up(n * sizeof(double), 256) + 9 * round_up(n * sizeof(int), 256);
+  b += 3 * round_up((size_t)dim * sizeof(float), 256) + round_up((size_t)((dim + kFoldCols - 1) / kFoldCols) * sizeof(int), 256);
+  return b;
+}
+
 int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigned char *d_out_u8,
                   void *d_ws, size_t ws_bytes, hipStream_t stream) {
   if (rows < 0 || dim <= 0) return set_error(SPV_ERR_INVALID, "bad shape");
@@ -240,8 +694,49 @@ int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigne
   float *stats = static_cast<float *>(d_ws);
   const int dim16 = (dim + 15) / 16 * 16;
   ProfScope prof("normalize", stream);
-  hipLaunchKernelGGL(column_stats_kernel, dim3((dim + kStatCols - 1) / kStatCols), dim3(kStatThreads), 0, stream, d_x,
-                     rows, dim, stats);
+  const int nblk = (dim + kStatCols - 1) / kStatCols;
+  static const bool serial_only = [] {
+    const char *e = getenv("SPECTAVI_NORMALIZE_SERIAL");
+    return e && *e == '1';
+  }();
+  const int *only_blocks = nullptr;
+  if (!serial_only && rows >= kFoldMinRows && ws_bytes >= normalize_workspace_bytes_rows(rows, dim)) {
+    const int nch = fold_chunks(rows);
+    const size_t n = (size_t)nch * dim;
+    unsigned char *p = static_cast<unsigned char *>(d_ws) + normalize_workspace_bytes(dim);
+    auto take = [&](size_t bytes) {
+      unsigned char *q = p;
+      p += round_up(bytes, 256);
+      return q;
+    };
+    FoldBufs fb;
+    fb.csum = reinterpret_cast<double *>(take(n * sizeof(double)));
+    fb.cpmin = reinterpret_cast<double *>(take(n * sizeof(double)));
+    fb.cpmax = reinterpret_cast<double *>(take(n * sizeof(double)));
+    fb.cvmax = reinterpret_cast<float *>(take(n * sizeof(float)));
+    fb.cvmin = reinterpret_cast<float *>(take(n * sizeof(float)));
+    fb.cfinite = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.eguess = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.d0 = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.d1 = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.tlo = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.thi = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.qq = reinterpret_cast<int *>(take(n * sizeof(int)));
+    fb.colvmax = reinterpret_cast<float *>(take((size_t)dim * sizeof(float)));
+    fb.colvmin = reinterpret_cast<float *>(take((size_t)dim * sizeof(float)));
+    fb.blockserial = reinterpret_cast<int *>(take((size_t)nblk * sizeof(int)));
+    int *colserial = reinterpret_cast<int *>(take((size_t)dim * sizeof(int)));
+    fb.nchunks = nch;
+    const dim3 grid((unsigned)nblk, (unsigned)nch);
+    hipLaunchKernelGGL(colsum_stats_kernel, grid, dim3(kFoldThreads), 0, stream, d_x, rows, dim, fb);
+    hipLaunchKernelGGL(colsum_plan_kernel, dim3(dim), dim3(64), 0, stream, nch, dim, fb, colserial);
+    hipLaunchKernelGGL(colsum_blockmode_kernel, dim3((nblk + 63) / 64), dim3(64), 0, stream, dim, colserial, fb.blockserial);
+    hipLaunchKernelGGL(colsum_fold_kernel, grid, dim3(kFoldThreads), 0, stream, d_x, rows, dim, fb);
+    hipLaunchKernelGGL(colsum_chain_kernel, dim3(dim), dim3(64), 0, stream, d_x, rows, dim, nch, fb, stats);
+    only_blocks = fb.blockserial;
+  }
+  hipLaunchKernelGGL(column_stats_kernel, dim3(nblk), dim3(kStatThreads), 0, stream, d_x, rows, dim, stats,
+                     only_blocks);
   hipLaunchKernelGGL(normalize_apply_kernel, dim3(2048), dim3(256), 0, stream, d_x, rows, dim, dim16, stats,
                      d_out_f32, d_out_u8);
   SPV_HIP_CHECK(hipGetLastError());

@@ -1073,11 +1073,12 @@ int host_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *o
   SPV_TRY(dx.alloc((size_t)rows * dim * sizeof(float)));
   if (out_f32) SPV_TRY(df.alloc((size_t)rows * dim16 * sizeof(float)));
   if (out_u8) SPV_TRY(du.alloc((size_t)rows * dim16));
-  SPV_TRY(ws.alloc(normalize_workspace_bytes(dim)));
+  const size_t wsb = normalize_workspace_bytes_rows(rows, dim);
+  SPV_TRY(ws.alloc(wsb));
   hipStream_t st = hipStreamPerThread;  // concurrent callers (ctypes drops the GIL) do not serialise on the null stream
   SPV_HIP_CHECK(hipMemcpyAsync(dx.p, x, (size_t)rows * dim * sizeof(float), hipMemcpyHostToDevice, st));
   SPV_TRY(normalize_run(dx.as<float>(), rows, dim, out_f32 ? df.as<float>() : nullptr,
-                        out_u8 ? du.as<unsigned char>() : nullptr, ws.p, normalize_workspace_bytes(dim), st));
+                        out_u8 ? du.as<unsigned char>() : nullptr, ws.p, wsb, st));
   if (out_f32)
     SPV_HIP_CHECK(hipMemcpyAsync(out_f32, df.p, (size_t)rows * dim16 * sizeof(float), hipMemcpyDeviceToHost, st));
   if (out_u8) SPV_HIP_CHECK(hipMemcpyAsync(out_u8, du.p, (size_t)rows * dim16, hipMemcpyDeviceToHost, st));
@@ -1530,6 +1531,9 @@ int spv_normalize(const float *x, int rows, int dim, float *out_f32, uint8_t *ou
   return host_guard([&] { return host_normalize(x, rows, dim, out_f32, out_u8); });
 }
 size_t spv_normalize_workspace_bytes(int dim) { return dim <= 0 ? 0 : normalize_workspace_bytes(dim); }
+size_t spv_normalize_workspace_bytes_rows(int rows, int dim) {
+  return (dim <= 0 || rows < 0) ? 0 : normalize_workspace_bytes_rows(rows, dim);
+}
 int spv_normalize_device(const float *d_x, int rows, int dim, float *d_out_f32, uint8_t *d_out_u8,
                          void *d_ws, size_t ws_bytes, void *stream) {
   clear_error();

@@ -89,6 +89,9 @@ int gather_match_coords_run(const float *d_geom_x, const float *d_geom_y, const 
                             hipStream_t stream);
 
 size_t normalize_workspace_bytes(int dim);
+// the larger workspace with which normalize_run folds the column sums of a big table instead of
+// walking them (same results; with the smaller one it walks)
+size_t normalize_workspace_bytes_rows(int rows, int dim);
 int normalize_run(const float *d_x, int rows, int dim, float *d_out_f32, unsigned char *d_out_u8,
                   void *d_ws, size_t ws_bytes, hipStream_t stream);
 

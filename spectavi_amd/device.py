@@ -336,8 +336,8 @@ def ransac_fit(x0, x1, required_percent_inliers=.9, reprojection_error_allowed=.
             'inlier_idx': idx[:n.value].copy(), 'best_try': bt.value, 'best_root': br.value, 'tries_run': ran.value}
 
 
-clib.spv_normalize_workspace_bytes.restype = ct.c_size_t
-clib.spv_normalize_workspace_bytes.argtypes = [ct.c_int]
+clib.spv_normalize_workspace_bytes_rows.restype = ct.c_size_t
+clib.spv_normalize_workspace_bytes_rows.argtypes = [ct.c_int, ct.c_int]
 clib.spv_normalize_device.restype = ct.c_int
 clib.spv_normalize_device.argtypes = [_vp, ct.c_int, ct.c_int, _vp, _vp, _vp, ct.c_size_t, _vp]
 
@@ -352,7 +352,7 @@ def normalize(x, want_float=True, want_ubyte=False, workspace=None):
     out = torch.empty((rows, dim16), dtype=torch.float32, device=x.device) if want_float else None
     u8 = torch.empty((rows, dim16), dtype=torch.uint8, device=x.device) if want_ubyte else None
     with _on_device_of(x) as stream:
-        ws = (workspace or _default_ws).get(clib.spv_normalize_workspace_bytes(dim), x.device)
+        ws = (workspace or _default_ws).get(clib.spv_normalize_workspace_bytes_rows(rows, dim), x.device)
         check(clib.spv_normalize_device(x.data_ptr(), rows, dim, out.data_ptr() if want_float else None,
                                         u8.data_ptr() if want_ubyte else None, ws.data_ptr(), ws.numel(), stream))
     if want_float and want_ubyte:

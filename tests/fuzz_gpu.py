@@ -217,7 +217,8 @@ def fuzz_normalize(seed, budget, only_case=None):
     t0, n = time.time(), 0 if only_case is None else only_case
     while time.time() - t0 < budget:
         rng = np.random.default_rng([seed, 5, n])
-        rows = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 511, 512, 513, 1023, 1025, rng.integers(2, 40000)]))
+        rows = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 511, 512, 513, 1023, 1025, 65535, 65536, 65537, rng.integers(2, 40000),
+                               rng.integers(65536, 300000)]))   # 65536 rows and up take the folded column sums
         dim = int(rng.choice([2, 4, 15, 16, 17, 128, 132, 144, rng.integers(2, 300)]))   # dim 1 is refused
         kind = int(rng.integers(0, 3))
         if kind == 0:

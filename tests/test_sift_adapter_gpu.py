@@ -81,3 +81,60 @@ def test_normalize_single_column_is_refused():
         feature.normalize_to_ubyte_and_multiple_16_dim_gpu(np.arange(100, dtype=np.float32)[:, None])
     one = feature.normalize_to_ubyte_and_multiple_16_dim_gpu(np.array([[3.0, 5.0]], np.float32))  # one row is fine
     assert one.shape == (1, 16)
+
+
+def _adversarial_table(rng, rows):
+    """One column per way a float32 running sum can behave: monotone integer data crossing binades
+    (ties to even once the sum passes 2^24), odd integers and x.5 values (every add a tie), pixel
+    coordinates, angles (a random walk around zero: binade changes and cancellation), symmetric
+    mixed signs, huge / tiny mixtures, exact cancellation, subnormals, signed zeros, negative drift."""
+    cols = [rng.integers(0, 256, rows), rng.integers(0, 65536, rows), 2 * rng.integers(0, 5000, rows) + 1,
+            rng.integers(0, 2000, rows) + 0.5, rng.uniform(0, 1280, rows), rng.uniform(1, 8, rows),
+            rng.uniform(-np.pi, np.pi, rows), rng.integers(-1000, 1001, rows),
+            np.where(rng.random(rows) < 0.01, 1e7, 1e-3), 2.0 ** rng.integers(-10, 20, rows),
+            np.tile(np.array([1e6, -1e6, 3.25, -3.0]), rows // 4 + 1)[:rows], rng.integers(0, 1000, rows) * 1e-45,
+            np.where(rng.random(rows) < 0.5, 0.0, -0.0), -rng.uniform(0, 300, rows),
+            rng.standard_normal(rows) * 1e4 + 1e6, rng.standard_normal(rows) * 3e-2 - 1e-2,
+            np.full(rows, 16777216.0), np.full(rows, 3.0), rng.standard_normal(rows) * 100 + 50]
+    x = np.stack(cols, axis=1).astype(np.float32)
+    x[0, -1] += 1.0
+    return x
+
+
+@pytest.mark.parametrize("rows,seed", [(65536, 1), (65537, 2), (100003, 3), (262144, 4), (1000000, 5), (70001, 6)])
+def test_normalize_folded_column_sums_are_numpys_bits(rows, seed):
+    """Tables of 65536 rows and more take the folded column sums (adapter.hip: per 1024-row chunk a
+    parity -> (increment, parity) function, applied only where the true running sum provably stays
+    in one binade).  Every column type that could break the argument, against numpy -- the reference
+    function itself (spectavi/feature.py:384-407) -- bit for bit; and against the walking kernel."""
+    import os
+    from spectavi_amd import feature
+    rng = np.random.default_rng(seed)
+    x = _adversarial_table(rng, rows)
+    with np.errstate(all='ignore'):
+        want = feature.normalize_to_ubyte_and_multiple_16_dim(x)
+    got, u8 = feature.normalize_to_ubyte_and_multiple_16_dim_gpu(x, want_ubyte=True)
+    bad = np.flatnonzero(~np.all((got == want) | (np.isnan(got) & np.isnan(want)), axis=0))
+    assert bad.size == 0, "columns %s differ from numpy" % bad.tolist()
+    finite = ~np.isnan(want).any(axis=0)
+    assert np.array_equal(u8[:, finite], (want[:, finite] + 128).astype('uint8'))
+    # the means themselves (a column's normalised values could hide a last-bit difference of its mean)
+    import torch
+    from spectavi_amd import device as spv
+    xt = torch.from_numpy(x).cuda()
+    dev = spv.normalize(xt).cpu().numpy()
+    assert np.array_equal(dev, got, equal_nan=True)
+
+
+def test_normalize_with_inf_and_nan_columns():
+    from spectavi_amd import feature
+    rng = np.random.default_rng(9)
+    x = rng.uniform(0, 100, (90000, 6)).astype(np.float32)
+    x[10000, 1] = np.inf
+    x[7000, 2] = np.nan
+    x[89999, 3] = -np.inf
+    x[0, 4] = np.nan
+    with np.errstate(all='ignore'):
+        want = feature.normalize_to_ubyte_and_multiple_16_dim(x)
+    got = feature.normalize_to_ubyte_and_multiple_16_dim_gpu(x)
+    assert np.array_equal(got, want, equal_nan=True)
