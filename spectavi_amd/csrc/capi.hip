@@ -998,9 +998,10 @@ int host_ransac_fit(const double *x0, const double *x1, int npt, double required
   int ok = 0, ninl = 0, bt = -1, br = -1, ran = 0;
   const int rc = ransac_fit_run(d_x0, d_x1, npt, required_percent, max_error, max_tries, find_best, ratio_allowed, next,
                                 &ok, essential, camera, &ninl, mask.data(), &bt, &br, &ran, ws.p, wsb, batch, st);
-  // the workspace goes back to the pool below: nothing may still be running on a caller's stream
-  // (DevBuf's destructor only drains this thread's own stream)
-  if (rc != SPV_OK && st != hipStreamPerThread) (void)hipStreamSynchronize(st);
+  // the workspace goes back to the pool below: nothing may still be queued on a caller's stream
+  // (DevBuf's destructor only drains this thread's own stream; error paths and a call with zero
+  // tries return without the per-batch synchronisation)
+  if (st != hipStreamPerThread) (void)hipStreamSynchronize(st);
   SPV_TRY(rc);
   *success = ok;
   *inlier_percent = (double)ninl / (double)npt;
