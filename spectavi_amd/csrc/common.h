@@ -113,9 +113,11 @@ int gather_widen_run(const void *d_recv, long long total, int G, long long max_c
 size_t dlt_score_workspace_bytes(int nhyp, long long npt);
 // d_ws (may be NULL / short: the scorer then runs in one pass, same results) holds the work list of
 // the solves that are deferred to the second pass
+// d_live / d_nlive (may be NULL): score only the hypotheses 4 f .. 4 f + 3 of the *d_nlive candidates f
+// listed in d_live (device memory); the counts of the others stay 0, their mask rows unwritten
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask, void *d_ws,
-                  size_t ws_bytes, hipStream_t stream);
+                  size_t ws_bytes, hipStream_t stream, const int *d_live = nullptr, const int *d_nlive = nullptr);
 
 
 // ---- RANSAC candidate processing (dlt.hip): gate, E, four cameras, scoring, best camera ----

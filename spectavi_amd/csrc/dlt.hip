@@ -363,26 +363,22 @@ struct WorkList {
   unsigned int segment;         // entries per shard; 0 = no list
 };
 
+// cand / ncand (RANSAC candidate processing): the candidates that passed the gate, in any order;
+// row y then scores camera y % 4 of candidate cand[y / 4], and the grid has only as many rows
+// (at most 2 048, each workgroup walking y, y + gridDim.y, ...) as a batch plausibly needs: almost
+// every candidate of a RANSAC batch is gated, and a grid row per gated camera is a row of workgroups
+// that start only to find a NaN and leave -- 500 000 of them per batch of 5 461 tries, 1.2 of the
+// batch's 2 ms in launch rate alone.  Without a list row y is hypothesis y.
 template <bool TWO_PASS>
 __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
-    Cameras cam0, const double *__restrict__ p1s, long long npt, const double *__restrict__ x,
+    Cameras cam0, const double *__restrict__ p1s, int nhyp, long long npt, const double *__restrict__ x,
     const double *__restrict__ xp, double max_error, int *__restrict__ counts,
-    unsigned char *__restrict__ mask, WorkList wl) {
+    unsigned char *__restrict__ mask, WorkList wl, const int *__restrict__ cand, const int *__restrict__ ncand) {
   __shared__ double sx[kDltThreads * 3];
   __shared__ double sxp[kDltThreads * 3];
-  const int h = blockIdx.y;
-  Cameras cam;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    cam.p0[i] = cam0.p0[i];
-    cam.p1[i] = p1s[(size_t)h * 12 + i];  // wave-uniform
-  }
   const long long base = (long long)blockIdx.x * kDltThreads;
   const long long nblk = min((long long)kDltThreads, npt - base);
-  if (cam.p1[0] != cam.p1[0]) {  // NaN camera = a gated RANSAC candidate (workgroup-uniform): nothing is an inlier
-    if (mask && threadIdx.x < nblk) mask[(size_t)h * npt + base + threadIdx.x] = 0;
-    return;
-  }
+  // the workgroup's correspondences are staged once and serve every grid row it walks
   for (int e = threadIdx.x; e < nblk * 3; e += kDltThreads) {
     sx[e] = x[base * 3 + e];
     sxp[e] = xp[base * 3 + e];
@@ -390,43 +386,57 @@ __global__ __launch_bounds__(kDltThreads) void dlt_score_kernel(
   __syncthreads();
   const int t = threadIdx.x;
   const bool live = t < nblk;
-  double A[4][4], xv[4], u = 0, v = 0, up = 0, vp = 0;
-  bool solved = true;  // dead lanes have nothing to solve
-  if (live) {
-    dlt_matrix(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1], sxp[3 * t + 2], A, u, v,
-               up, vp);
-    solved = null_gs_inverse_iteration(A, xv);
-  }
-  bool deferred = false;
-  if (TWO_PASS) {
-    // slow lanes of the wave -> work list
-    const unsigned long long slow = __ballot(!solved);
-    if (slow) {
-      const int lane = threadIdx.x & 63;
-      const unsigned int shard = (blockIdx.y * gridDim.x + blockIdx.x) * (kDltThreads / 64) + (threadIdx.x >> 6);
-      const unsigned int sh = shard % kListShards;
-      unsigned int first = 0;
-      if (lane == 0) first = atomicAdd(wl.count + sh * kCountStride, (unsigned int)__popcll(slow));
-      first = __shfl(first, 0, 64);
-      if (!solved) {
-        const unsigned int slot = first + (unsigned int)__popcll(slow & ((1ull << lane) - 1ull));
-        if (slot < wl.segment) {
-          wl.entries[(size_t)sh * wl.segment + slot] = ((unsigned long long)h << 40) | (unsigned long long)(base + t);
-          deferred = true;
+  const int nrows = cand ? 4 * *ncand : nhyp;  // workgroup-uniform
+  for (int y = blockIdx.y; y < nrows; y += gridDim.y) {
+    const int h = cand ? 4 * cand[y >> 2] + (y & 3) : y;
+    Cameras cam;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      cam.p0[i] = cam0.p0[i];
+      cam.p1[i] = p1s[(size_t)h * 12 + i];  // wave-uniform
+    }
+    if (cam.p1[0] != cam.p1[0]) {  // NaN camera = a gated RANSAC candidate (workgroup-uniform): nothing is an inlier
+      if (mask && live) mask[(size_t)h * npt + base + t] = 0;
+      continue;
+    }
+    double A[4][4], xv[4], u = 0, v = 0, up = 0, vp = 0;
+    bool solved = true;  // dead lanes have nothing to solve
+    if (live) {
+      dlt_matrix(cam, sx[3 * t], sx[3 * t + 1], sx[3 * t + 2], sxp[3 * t], sxp[3 * t + 1], sxp[3 * t + 2], A, u, v,
+                 up, vp);
+      solved = null_gs_inverse_iteration(A, xv);
+    }
+    bool deferred = false;
+    if (TWO_PASS) {
+      // slow lanes of the wave -> work list
+      const unsigned long long slow = __ballot(!solved);
+      if (slow) {
+        const int lane = threadIdx.x & 63;
+        const unsigned int shard = ((unsigned)y * gridDim.x + blockIdx.x) * (kDltThreads / 64) + (threadIdx.x >> 6);
+        const unsigned int sh = shard % kListShards;
+        unsigned int first = 0;
+        if (lane == 0) first = atomicAdd(wl.count + sh * kCountStride, (unsigned int)__popcll(slow));
+        first = __shfl(first, 0, 64);
+        if (!solved) {
+          const unsigned int slot = first + (unsigned int)__popcll(slow & ((1ull << lane) - 1ull));
+          if (slot < wl.segment) {
+            wl.entries[(size_t)sh * wl.segment + slot] = ((unsigned long long)h << 40) | (unsigned long long)(base + t);
+            deferred = true;
+          }
         }
       }
     }
+    if (!solved && !deferred) null_jacobi(A, xv);  // in place: no work list, or it is full
+    bool inlier = false;
+    if (live && !deferred) {
+      double X[4];
+      dlt_finish(xv, X);
+      inlier = score_inlier(cam, X, u, v, up, vp, max_error);
+      if (mask) mask[(size_t)h * npt + base + t] = inlier ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(inlier);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[h], __popcll(bal));
   }
-  if (!solved && !deferred) null_jacobi(A, xv);  // in place: no work list, or it is full
-  bool inlier = false;
-  if (live && !deferred) {
-    double X[4];
-    dlt_finish(xv, X);
-    inlier = score_inlier(cam, X, u, v, up, vp, max_error);
-    if (mask) mask[(size_t)h * npt + base + t] = inlier ? 1 : 0;
-  }
-  const unsigned long long bal = __ballot(inlier);
-  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[h], __popcll(bal));
 }
 
 // Second pass: one lane per work-list entry, method 1.
@@ -627,7 +637,8 @@ __device__ __forceinline__ void mat3_mul(const double (&A)[3][3], const double (
 // candidates with a NaN entry) get NaN cameras (the scoring kernel skips them) and gated[f] = 1.
 __global__ __launch_bounds__(kDltThreads) void essential_cameras_kernel(
     const double *__restrict__ Fs, int nF, double ratio_allowed, double *__restrict__ cams,
-    double *__restrict__ ratio_out, double *__restrict__ E_out, int *__restrict__ gated) {
+    double *__restrict__ ratio_out, double *__restrict__ E_out, int *__restrict__ gated,
+    int *__restrict__ live, int *__restrict__ nlive) {
   const int f = blockIdx.x * kDltThreads + threadIdx.x;
   if (f >= nF) return;
   double F[3][3], U[3][3], S[3], V[3][3];
@@ -654,6 +665,7 @@ __global__ __launch_bounds__(kDltThreads) void essential_cameras_kernel(
     return;
   }
   gated[f] = 0;
+  live[atomicAdd(nlive, 1)] = f;  // any order: every (camera, correspondence) result stands alone
   double Ud[3][3], Vt[3][3], E[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -742,6 +754,7 @@ size_t ransac_workspace_bytes(int nF, long long npt, bool want_mask) {
   size_t b = round_up((size_t)nF * 48 * sizeof(double), 256);      // cameras
   b += round_up((size_t)nF * 4 * sizeof(int), 256);                 // inlier counts
   b += round_up((size_t)nF * sizeof(int), 256);                     // gate flags
+  b += round_up(((size_t)nF + 1) * sizeof(int), 256);               // the candidates that passed the gate + their count
   if (want_mask) b += round_up((size_t)nF * 4 * (size_t)npt, 256);  // per-camera inlier masks
   b += dlt_score_workspace_bytes(4 * nF, npt);                      // the scorer's work list
   return b;
@@ -767,18 +780,23 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
   ws += round_up((size_t)nF * 4 * sizeof(int), 256);
   int *gated = reinterpret_cast<int *>(ws);
   ws += round_up((size_t)nF * sizeof(int), 256);
+  int *nlive = reinterpret_cast<int *>(ws);  // [0] = count, [1..] = candidate ids
+  int *live = nlive + 1;
+  ws += round_up(((size_t)nF + 1) * sizeof(int), 256);
   unsigned char *mask4 = d_mask ? ws : nullptr;
   if (d_mask) ws += round_up((size_t)nF * 4 * (size_t)npt, 256);
   const size_t score_ws = dlt_score_workspace_bytes(4 * nF, npt);
   const int fblocks = (nF + kDltThreads - 1) / kDltThreads;
+  SPV_HIP_CHECK(hipMemsetAsync(nlive, 0, sizeof(int), stream));
   {
     ProfScope prof("ransac_cameras", stream);
     hipLaunchKernelGGL(essential_cameras_kernel, dim3(fblocks), dim3(kDltThreads), 0, stream, d_Fs, nF,
-                       ratio_allowed, cams, d_ratio, d_E, gated);
+                       ratio_allowed, cams, d_ratio, d_E, gated, live, nlive);
     SPV_HIP_CHECK(hipGetLastError());
   }
   const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // Camera(): Identity(3,4), src/Camera.h:27
-  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, ws, score_ws, stream));
+  // a mask row of a gated camera is never looked at (best_mask_kernel only reads the best camera's)
+  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, ws, score_ws, stream, live, nlive));
   hipLaunchKernelGGL(select_camera_kernel, dim3(fblocks), dim3(kDltThreads), 0, stream, counts, gated, cams, nF, npt,
                      required_percent, find_best, d_success, d_inlier_count, d_best_cam, d_best_P, d_counts4);
   SPV_HIP_CHECK(hipGetLastError());
@@ -807,7 +825,7 @@ size_t dlt_score_workspace_bytes(int nhyp, long long npt) {
 
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask, void *d_ws,
-                  size_t ws_bytes, hipStream_t stream) {
+                  size_t ws_bytes, hipStream_t stream, const int *d_live, const int *d_nlive) {
   if (npt < 0 || nhyp < 0) return set_error(SPV_ERR_INVALID, "negative count");
   if (!P0) return set_error(SPV_ERR_INVALID, "null camera pointer");
   if (nhyp == 0) return SPV_OK;
@@ -822,7 +840,7 @@ int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt
   const long long blocks = (npt + kDltThreads - 1) / kDltThreads;
   if (blocks > 0x7FFFFFFFLL) return set_error(SPV_ERR_INVALID, "too many points");
   ProfScope prof("dlt_score", stream);
-  const dim3 grid((unsigned)blocks, (unsigned)nhyp);
+  const dim3 grid((unsigned)blocks, (unsigned)(d_live ? std::min(nhyp, 2048) : nhyp));
   // a workspace too small for the work list is not an error: the scorer then runs in one pass
   WorkList wl{nullptr, nullptr, 0};
   if (d_ws && ws_bytes > kScoreCountBytes && (reinterpret_cast<uintptr_t>(d_ws) & 7) == 0) {
@@ -832,14 +850,14 @@ int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt
                                                 score_segment(nhyp, npt));
   }
   if (wl.segment == 0) {
-    hipLaunchKernelGGL(dlt_score_kernel<false>, grid, dim3(kDltThreads), 0, stream, cam0, d_p1s, npt, d_x, d_xp,
-                       max_error, d_counts, d_mask, wl);
+    hipLaunchKernelGGL(dlt_score_kernel<false>, grid, dim3(kDltThreads), 0, stream, cam0, d_p1s, nhyp, npt, d_x, d_xp,
+                       max_error, d_counts, d_mask, wl, d_live, d_nlive);
     SPV_HIP_CHECK(hipGetLastError());
     return SPV_OK;
   }
   SPV_HIP_CHECK(hipMemsetAsync(wl.count, 0, kScoreCountBytes, stream));
-  hipLaunchKernelGGL(dlt_score_kernel<true>, grid, dim3(kDltThreads), 0, stream, cam0, d_p1s, npt, d_x, d_xp,
-                     max_error, d_counts, d_mask, wl);
+  hipLaunchKernelGGL(dlt_score_kernel<true>, grid, dim3(kDltThreads), 0, stream, cam0, d_p1s, nhyp, npt, d_x, d_xp,
+                     max_error, d_counts, d_mask, wl, d_live, d_nlive);
   SPV_HIP_CHECK(hipGetLastError());
   // the list's length is only known on the device: a grid that covers a full list, strided
   const unsigned fb = (unsigned)std::min<unsigned long long>(((unsigned long long)kListShards * wl.segment + kDltThreads - 1) / kDltThreads,

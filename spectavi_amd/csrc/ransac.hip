@@ -431,19 +431,26 @@ int ransac_fit_run(const double *d_x0, const double *d_x1, long long npt, double
     return set_error(SPV_ERR_INVALID, "workspace too small: %zu < %zu", ws_bytes, ransac_fit_workspace_bytes(batch, npt));
   const FitBuffers b = carve(d_ws, batch, npt);
   SPV_HIP_CHECK(hipMemsetAsync(b.state, 0, sizeof(FitState), stream));
-  std::vector<int> host_samples((size_t)batch * 7);
+  // two host buffers: the subsets of the next batch are drawn while the device works on this one
+  std::vector<int> host_a((size_t)batch * 7), host_b((size_t)batch * 7);
+  int *cur = host_a.data(), *nxt = host_b.data();
   FitState head;  // only the four ints are read back per batch
   head.found = head.success = head.count = 0;
   head.cand = -1;
   int done = 0;
   // easy problems succeed within a few tries: start small, grow to the full batch
   int step = std::min(batch, 256);
+  auto draw = [&](int first, int n, int *dst) -> int {
+    next_samples(first, n, dst);
+    for (size_t i = 0; i < (size_t)n * 7; ++i)
+      if (dst[i] < 0 || dst[i] >= npt) return set_error(SPV_ERR_INVALID, "sample index %d outside [0, %lld)", dst[i], npt);
+    return SPV_OK;
+  };
+  if (max_tries > 0) SPV_TRY(draw(0, std::min(step, max_tries), cur));
   while (done < max_tries) {
     const int n = std::min(step, max_tries - done);
-    next_samples(done, n, host_samples.data());
-    for (size_t i = 0; i < (size_t)n * 7; ++i)
-      if (host_samples[i] < 0 || host_samples[i] >= npt) return set_error(SPV_ERR_INVALID, "sample index %d outside [0, %lld)", host_samples[i], npt);
-    SPV_HIP_CHECK(hipMemcpyAsync(b.samples, host_samples.data(), (size_t)n * 7 * sizeof(int), hipMemcpyHostToDevice, stream));
+    // (pageable source: the copy has left `cur` when the call returns)
+    SPV_HIP_CHECK(hipMemcpyAsync(b.samples, cur, (size_t)n * 7 * sizeof(int), hipMemcpyHostToDevice, stream));
     {
       ProfScope prof("seven_point", stream);
       hipLaunchKernelGGL(seven_point_kernel<true>, dim3((n + kFitThreads - 1) / kFitThreads), dim3(kFitThreads), 0, stream,
@@ -460,10 +467,14 @@ int ransac_fit_run(const double *d_x0, const double *d_x1, long long npt, double
       SPV_HIP_CHECK(hipGetLastError());
     }
     SPV_HIP_CHECK(hipMemcpyAsync(&head, b.state, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    SPV_HIP_CHECK(hipStreamSynchronize(stream));  // also: host_samples is free to be refilled
+    const int next_step = std::min(batch, step * 4);
+    const int n_next = std::min(next_step, max_tries - (done + n));
+    if (n_next > 0) SPV_TRY(draw(done + n, n_next, nxt));  // while the batch runs
+    SPV_HIP_CHECK(hipStreamSynchronize(stream));
     done += n;
     if (head.success) break;
-    step = std::min(batch, step * 4);
+    step = next_step;
+    std::swap(cur, nxt);
   }
   if (tries_run) *tries_run = done;
   *success = head.success;

@@ -319,7 +319,7 @@ def ransac_fit():
     for npt, tries in ((500, 40000), (2000, 20000), (20000, 4000)):
         x0, x1, E, out_idx = mc.two_view_scene(rng, npt=npt, outlier_fraction=0.4, noise=1e-4)
         kw = dict(reprojection_error_allowed=1e-3, singular_value_ratio_allowed=3e-2)
-        mvg.ransac_fit(x0, x1, required_percent_inliers=0.999, maximum_tries=300, seed=1, **kw)  # warm-up
+        mvg.ransac_fit(x0, x1, required_percent_inliers=0.999, maximum_tries=tries, seed=1, **kw)  # warm-up (same workspace size)
         spv.profile_reset()
         spv.profile_enable(True)
         t0 = time.perf_counter()
