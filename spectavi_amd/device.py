@@ -358,3 +358,24 @@ def normalize(x, want_float=True, want_ubyte=False, workspace=None):
     if want_float and want_ubyte:
         return out, u8
     return out if want_float else u8
+
+
+clib.spv_seven_point_device.restype = ct.c_int
+clib.spv_seven_point_device.argtypes = [_vp, _vp, ct.c_int, _vp, _vp, _vp, _vp]
+
+
+def seven_point(x, xp, want_basis=False):
+    """Seven-point algorithm for n 7-subsets resident in HBM (reference src/FundamentalMatrixFitter.h:108-246):
+    x, xp CUDA float64 [n,7,2] euclidean.  Returns (nroot int32 [n], Fs float64 [n,3,3,3], NaN in the slots of
+    missing roots) and, with want_basis, the null-space pair [n,2,3,3].  Asynchronous on the current stream."""
+    _need(x, torch.float64, "x")
+    _need(xp, torch.float64, "xp")
+    assert x.dim() == 3 and x.shape[1:] == (7, 2) and xp.shape == x.shape
+    n = x.shape[0]
+    nroot = torch.empty(n, dtype=torch.int32, device=x.device)
+    Fs = torch.empty((n, 3, 3, 3), dtype=torch.float64, device=x.device)
+    basis = torch.empty((n, 2, 3, 3), dtype=torch.float64, device=x.device) if want_basis else None
+    with _on_device_of(x, xp) as stream:
+        check(clib.spv_seven_point_device(x.data_ptr(), xp.data_ptr(), n, Fs.data_ptr(), nroot.data_ptr(),
+                                          basis.data_ptr() if want_basis else None, stream))
+    return (nroot, Fs, basis) if want_basis else (nroot, Fs)

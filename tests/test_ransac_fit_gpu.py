@@ -55,6 +55,19 @@ def test_seven_point_batch_matches_oracle_and_numpy(oracle, kind, n):
     assert same_basis >= 0.99 * n  # unfused arithmetic on both sides: the null-space pair is the same bits
 
 
+def test_seven_point_device_resident_equals_host_entry():
+    import torch
+    from spectavi_amd import device as spv
+    from spectavi_amd import mvg
+    rng = np.random.default_rng(21)
+    x, xp = _euclid(rng, 777, "randn")
+    nroot, Fs, basis = mvg.seven_point_batch(x, xp, return_basis=True)
+    dn, dF, db = spv.seven_point(torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda(), want_basis=True)
+    assert np.array_equal(dn.cpu().numpy(), nroot)
+    assert np.array_equal(dF.cpu().numpy(), Fs, equal_nan=True)
+    assert np.array_equal(db.cpu().numpy(), basis)
+
+
 def test_seven_point_algorithm_reference_tests():
     """reference test/test_mvg.py:127-160 through the drop-in symbol."""
     from spectavi_amd import mvg
