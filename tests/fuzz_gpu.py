@@ -312,9 +312,23 @@ def fuzz_ransac_fit(seed, budget, only_case=None):
         oo = o.ransac_fit(x0, x1, samples, **kw)
         dd = mvg.ransac_fit(x0, x1, samples=samples, **kw)
         same = (dd['success'] == oo['success'] and dd['best_try'] == oo['best_try'] and dd['best_root'] == oo['best_root']
-                and dd['inlier_percent'] == oo['inlier_percent'] and np.array_equal(dd['inlier_idx'], oo['inlier_idx']))
+                and dd['inlier_percent'] == oo['inlier_percent'])
         if same and oo['best_try'] >= 0:
-            same = mc.parallel(dd['essential'], oo['essential']) >= 1 - 1e-9 and min(np.abs(dd['camera'] - oo['camera']).max(), np.abs(dd['camera'] + oo['camera']).max()) < 1e-8  # -P is the same camera
+            same = mc.parallel(dd['essential'], oo['essential']) >= 1 - 1e-9
+            cam_same = min(np.abs(dd['camera'] - oo['camera']).max(), np.abs(dd['camera'] + oo['camera']).max()) < 1e-8  # -P is the same camera
+            if same and not (cam_same and np.array_equal(dd['inlier_idx'], oo['inlier_idx'])):
+                # Two of the four cameras with the same inlier count (junk models with one or two inliers): which
+                # of them comes first hangs on the signs of an SVD with two equal singular values, i.e. on the
+                # last bit of F, where device and oracle differ through libm's cos.  Then the oracle must give the
+                # device's answer when it is handed the device's F.
+                r = o.process_fundamental_matrix(dd['essential'], x0, x1, kw['singular_value_ratio_allowed'],
+                                                 kw['required_percent_inliers'], kw['reprojection_error_allowed'],
+                                                 kw['find_best_even_in_failure'])
+                same = (r['success'] and np.array_equal(r['inlier_idx'], dd['inlier_idx']) and
+                        min(np.abs(dd['camera'] - r['best_P']).max(), np.abs(dd['camera'] + r['best_P']).max()) < 1e-8 and
+                        sorted(r['counts4'])[-1] == sorted(r['counts4'])[-2])
+        elif same:
+            same = len(dd['inlier_idx']) == 0
         if not same:
             raise SystemExit("RANSAC FIT MISMATCH case=%d npt=%d outliers=%g tries=%d %r: device (try %d root %d, %d inliers) "
                              "oracle (try %d root %d, %d inliers)" % (n, npt, frac, tries, kw, dd['best_try'], dd['best_root'],
