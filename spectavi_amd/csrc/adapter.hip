@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kFoldThreads) void colsum_fold_kernel(const float *
 // One wave per column.  Every lane carries the same S.  The records of 64 chunks are fetched at
 // once (one per lane, coalesced) and handed to the sequential part with v_readlane, so the chain
 // never waits for memory between two chunks it can fold; lanes only differ when a chunk is walked
-// (each loads its own rows, v_readlane feeds them to the chain in row order).
+// (each loads its own rows, see walk_rows).
 __device__ __forceinline__ int rl_i(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
 // Rows [r0, r0 + n) of column c added to S one by one, in order: every lane loads its own row of a
