@@ -112,3 +112,60 @@ def dlt_sharded(P0, P1, x_shard, xp_shard, total_points, want_error=False, group
     if out.dim() == 1:
         out = out[:, None]
     return gather_rows(out, total_points, group, dst)
+
+
+def _default_fit_fn(x0, x1, samples, **kw):
+    from spectavi_amd import mvg
+    return mvg.ransac_fit(x0, x1, samples=samples, **kw)
+
+
+def ransac_fit_sharded(x0, x1, samples, group=None, local_fn=None, device=None, **kw):
+    """RANSAC tries sharded over the ranks (the reference spreads exactly this loop over OpenMP threads,
+    src/RansacFitter.h:163): the correspondences x0, x1 (numpy float64 [npt,3]) are replicated, rank r
+    evaluates the contiguous tries shard_bounds(len(samples), world, r) of `samples` (int32 [T,7], the same
+    array on every rank, e.g. mvg.ransac_sample(seed, npt, T)), and two small collectives rank the
+    per-rank results the way the serial loop would: the success with the lowest try index wins; without a
+    success (find_best_even_in_failure) the model with the most inliers, the earliest among equals.  Every
+    rank returns the winner's dict (mvg.ransac_fit's keys; best_try counts over all of `samples`).
+
+    local_fn(x0, x1, samples, **kw) defaults to the HIP path (mvg.ransac_fit); tests inject the CPU oracle.
+    `device`: where the exchanged tensors live (default: cuda for the nccl backend, else cpu)."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    local_fn = local_fn or _default_fit_fn
+    npt = x0.shape[0]
+    lo, hi = shard_bounds(len(samples), world, rank)
+    r = local_fn(x0, x1, samples[lo:hi], **kw)
+    found = r['best_try'] >= 0
+    count = len(r['inlier_idx']) if found else 0
+    head = torch.tensor([int(r['success']), (lo + r['best_try']) if found else -1, count], dtype=torch.int64, device=device)
+    heads = [torch.empty_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    heads = torch.stack(heads).cpu().numpy()
+    winners = [k for k in range(world) if heads[k, 0]]
+    if winners:
+        win = min(winners, key=lambda k: heads[k, 1])
+    else:
+        have = [k for k in range(world) if heads[k, 1] >= 0]
+        win = min(have, key=lambda k: (-heads[k, 2], heads[k, 1])) if have else -1
+    if win < 0:
+        return {'success': False, 'essential': None, 'camera': None, 'inlier_percent': 0.0,
+                'inlier_idx': np.zeros(0, np.int32), 'best_try': -1, 'best_root': -1}
+    model = torch.zeros(9 + 12 + 2, dtype=torch.float64, device=device)
+    idx = torch.full((npt,), -1, dtype=torch.int32, device=device)
+    if rank == win:
+        model[:9] = torch.from_numpy(np.ascontiguousarray(r['essential']).reshape(-1)).to(device)
+        model[9:21] = torch.from_numpy(np.ascontiguousarray(r['camera']).reshape(-1)).to(device)
+        model[21] = float(r['inlier_percent'])
+        model[22] = float(r['best_root'])
+        idx[:count] = torch.from_numpy(np.asarray(r['inlier_idx'], dtype=np.int32)).to(device)
+    src = win if group is None else dist.get_global_rank(group, win)
+    dist.broadcast(model, src=src, group=group)
+    dist.broadcast(idx, src=src, group=group)
+    model, idx = model.cpu().numpy(), idx.cpu().numpy()
+    return {'success': bool(heads[win, 0]), 'essential': model[:9].reshape(3, 3), 'camera': model[9:21].reshape(3, 4),
+            'inlier_percent': float(model[21]), 'inlier_idx': idx[:int(heads[win, 2])].copy(),
+            'best_try': int(heads[win, 1]), 'best_root': int(model[22])}

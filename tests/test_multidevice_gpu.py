@@ -362,3 +362,65 @@ def test_two_process_ranks_hip_compute_and_gather(oracle, tmp_path):
     ci, cd, _, _ = oracle.nn_cascading_hash(x.astype(np.float32) - 128, y.astype(np.float32) - 128, 9, 2, 2, d)
     assert np.array_equal(got["cidx"].view(np.uint64), ci) and np.array_equal(got["cdist"], cd)
     assert np.array_equal(got["X"], oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))
+
+
+def _hip_fit_rank(rank, world, port, out_path):
+    """One of `world` processes sharing GPU 0: the HIP RANSAC fit on its block of tries, the per-rank
+    winners ranked over gloo."""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spectavi_amd import mvg
+    from spectavi_amd.sharded import ransac_fit_sharded
+    from tests import mvg_checks as mc
+    rng = np.random.default_rng(5)
+    x0, x1, E, out_idx = mc.two_view_scene(rng, npt=400, outlier_fraction=0.45)
+    samples = mvg.ransac_sample(99, 400, 900)
+    out = {}
+    for name, kw in (("success", dict(required_percent_inliers=0.5, find_best_even_in_failure=False)),
+                     ("best", dict(required_percent_inliers=0.99, find_best_even_in_failure=True))):
+        kw.update(reprojection_error_allowed=1e-3, singular_value_ratio_allowed=3e-2)
+        r = ransac_fit_sharded(x0, x1, samples, **kw)
+        out[name + "_try"] = r['best_try']
+        out[name + "_root"] = r['best_root']
+        out[name + "_ok"] = r['success']
+        out[name + "_F"] = r['essential']
+        out[name + "_P"] = r['camera']
+        out[name + "_idx"] = r['inlier_idx']
+    if rank == world - 1:
+        np.savez(out_path, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_ranks_shard_the_ransac_tries(tmp_path):
+    """Three processes sharing GPU 0, each fitting its block of the 900 tries with the HIP path; the ranked
+    result is what one process gets from all 900 (the first success in try order / the earliest best model)."""
+    import socket
+    import torch.multiprocessing as mp
+    from spectavi_amd import mvg
+    from tests import mvg_checks as mc
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "fit.npz")
+    mp.spawn(_hip_fit_rank, args=(3, port, out), nprocs=3, join=True)
+    got = np.load(out)
+    rng = np.random.default_rng(5)
+    x0, x1, E, out_idx = mc.two_view_scene(rng, npt=400, outlier_fraction=0.45)
+    samples = mvg.ransac_sample(99, 400, 900)
+    for name, kw in (("success", dict(required_percent_inliers=0.5, find_best_even_in_failure=False)),
+                     ("best", dict(required_percent_inliers=0.99, find_best_even_in_failure=True))):
+        kw.update(reprojection_error_allowed=1e-3, singular_value_ratio_allowed=3e-2)
+        one = mvg.ransac_fit(x0, x1, samples=samples, **kw)
+        assert one['best_try'] >= 0
+        assert int(got[name + "_try"]) == one['best_try'] and int(got[name + "_root"]) == one['best_root']
+        assert bool(got[name + "_ok"]) == one['success']
+        assert np.array_equal(got[name + "_F"], one['essential']) and np.array_equal(got[name + "_P"], one['camera'])
+        assert np.array_equal(got[name + "_idx"], one['inlier_idx'])
+    assert bool(got["success_ok"]) and not bool(got["best_ok"])

@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -127,3 +128,52 @@ def test_sharded_cascade_and_dlt_world2_gloo(tmp_path):
         out = tmp_path / ("cd%d.txt" % nq)
         mp.spawn(_worker_cascade_dlt, args=(2, _free_port(), nq, str(out)), nprocs=2, join=True)
         assert out.read_text() == "ok"
+
+
+def _worker_fit(rank, world, port, out_path):
+    import torch.distributed as dist
+    from oracle import oracle as o
+    from spectavi_amd import sharded
+    from tests import mvg_checks as mc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    rng = np.random.default_rng(77)
+    x0, x1, E, out_idx = mc.two_view_scene(rng, npt=150, outlier_fraction=0.3)
+    samples = np.stack([rng.choice(np.arange(1, 150), 7, replace=False) for _ in range(90)]).astype(np.int32)
+
+    def local(x0_, x1_, s, **kw):
+        return o.ransac_fit(x0_, x1_, s, **kw)
+
+    for name, kw in (("success", dict(required_percent_inliers=0.6, reprojection_error_allowed=1e-3,
+                                      find_best_even_in_failure=False, singular_value_ratio_allowed=3e-2)),
+                     ("best", dict(required_percent_inliers=0.99, reprojection_error_allowed=1e-3,
+                                   find_best_even_in_failure=True, singular_value_ratio_allowed=3e-2)),
+                     ("none", dict(required_percent_inliers=0.99, reprojection_error_allowed=1e-3,
+                                   find_best_even_in_failure=False, singular_value_ratio_allowed=3e-2))):
+        r = sharded.ransac_fit_sharded(x0, x1, samples, local_fn=local, **kw)
+        serial = o.ransac_fit(x0, x1, samples, **kw)
+        ok = (r['success'] == serial['success'] and r['best_try'] == serial['best_try'] and
+              r['best_root'] == serial['best_root'] and np.array_equal(r['inlier_idx'], serial['inlier_idx']) and
+              r['inlier_percent'] == serial['inlier_percent'])
+        if serial['best_try'] >= 0:
+            ok = ok and np.array_equal(r['essential'], serial['essential']) and np.array_equal(r['camera'], serial['camera'])
+        else:
+            ok = ok and r['essential'] is None
+        res[name] = bool(ok)
+    if rank == 1:  # every rank holds the answer: let a non-zero rank report
+        np.save(out_path, np.array([res["success"], res["best"], res["none"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ransac_tries_sharded_gloo(tmp_path, world):
+    """RANSAC tries sharded over ranks (the loop the reference spreads over OpenMP threads): with the CPU
+    oracle as the local fit, every rank gets what the serial loop over all tries gives -- first success in
+    try order; else, with find_best_even_in_failure, the earliest model with the most inliers; else nothing."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "fit.npy")
+    mp.spawn(_worker_fit, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.load(out).all()
