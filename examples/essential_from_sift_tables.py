@@ -156,17 +156,31 @@ def host_pipeline(table0, table1, K, matching_method='bruteforce', min_ratio=1.7
 # ---------------------------------------------------------------------------------------------
 # the same steps with every intermediate resident in HBM
 # ---------------------------------------------------------------------------------------------
-def device_pipeline(table0, table1, K, min_ratio=1.75, ransac_quality='medium', maximum_tries=10000000, seed=0):
+def device_pipeline(table0, table1, K, min_ratio=1.75, ransac_quality='medium', maximum_tries=10000000, seed=0,
+                    matching_method='bruteforce', hash_seed=0x5eed):
     """SIFT tables (CUDA float32 [n,132]) -> split -> normalise the descriptor columns -> exact L1 2-NN
-    -> ratio test + compaction -> matched coordinates -> calibration -> RANSAC fit -> triangulation of
-    the inliers.  One upload (the tables), one small download (the model), one download of the points."""
+    (or the cascade hash + L1 refine) -> ratio test + compaction -> matched coordinates -> calibration
+    -> RANSAC fit -> triangulation of the inliers.  One upload (the tables), one small download (the
+    model), one download of the points."""
     import torch
     from spectavi_amd import device as spv
+    from spectavi_amd import feature
     geom0, desc0 = spv.split_sift_table(table0)
     geom1, desc1 = spv.split_sift_table(table1)
-    u0 = spv.normalize(desc0.to(torch.float32), want_float=False, want_ubyte=True)
-    u1 = spv.normalize(desc1.to(torch.float32), want_float=False, want_ubyte=True)
-    idx, dist = spv.l1k2(u0, u1)
+    if matching_method == 'bruteforce':
+        u0 = spv.normalize(desc0.to(torch.float32), want_float=False, want_ubyte=True)
+        u1 = spv.normalize(desc1.to(torch.float32), want_float=False, want_ubyte=True)
+        idx, dist = spv.l1k2(u0, u1)
+    elif matching_method == 'cascading-hash':
+        f0 = spv.normalize(desc0.to(torch.float32))
+        f1 = spv.normalize(desc1.to(torch.float32))
+        m = feature.auto_hash_bit_rate(f0.shape[0], f1.shape[0])  # the reference front-end's rule
+        if m < 4:
+            raise ValueError("tables too small for the cascade hash (the front-end falls back to brute force)")
+        d = torch.from_numpy(feature.generate_hash_dict(hash_seed, f0.shape[1], m, 2)).to(table0.device)
+        idx, dist = spv.cascade(f0, f1, d, g=2)
+    else:
+        raise ValueError(matching_method)
     matches, count = spv.ratio_test(idx, dist, min_ratio)
     p0, p1 = spv.match_coordinates(geom0, geom1, matches, count)
     n = int(count.item())
@@ -218,9 +232,9 @@ def main():
         d0, d1 = torch.from_numpy(t0).cuda(), torch.from_numpy(t1).cuda()
         torch.cuda.synchronize()
         s = time.perf_counter()
-        out = device_pipeline(d0, d1, K, a.min_ratio, a.ransac_quality)
+        out = device_pipeline(d0, d1, K, a.min_ratio, a.ransac_quality, matching_method=a.matching_method)
         torch.cuda.synchronize()
-        report("device-resident (bruteforce)", out, truth, time.perf_counter() - s)
+        report("device-resident (%s)" % a.matching_method, out, truth, time.perf_counter() - s)
 
 
 if __name__ == "__main__":

@@ -92,3 +92,19 @@ def test_example_pipeline_device_resident_equals_host_and_oracle(oracle, monkeyp
     assert np.allclose(ofit['essential'], dev['ransac']['essential'], rtol=1e-8, atol=1e-12)
     # points: the oracle's camera may be -P (same camera), its X is the same point
     assert np.abs(oX - dev['points']).max() < 1e-7
+
+
+def test_example_pipeline_device_resident_cascade():
+    """The same steps with the cascade hash as the matcher, device-resident: an approximate matcher
+    (it may miss pairs, it never invents one), the model is still the scene's."""
+    import torch
+    t0, t1, K, truth = ex.synthetic_sift_pair(seed=8, n_common=3000, n_extra=1500)
+    dev = ex.device_pipeline(torch.from_numpy(t0).cuda(), torch.from_numpy(t1).cuda(), K, maximum_tries=20000, seed=3,
+                             matching_method='cascading-hash')
+    m = dev['matches']
+    assert (truth['true_row0'][m[:, 0]] == m[:, 1]).mean() > 0.98 and len(m) > 0.5 * 3000
+    assert dev['ransac']['success']
+    rE = dev['ransac']['essential'] / np.linalg.svd(dev['ransac']['essential'])[1][0]
+    assert np.std(rE / truth['E']) < 1e-3
+    X_true = truth['X_of_row1'][m[dev['ransac']['inlier_idx'], 0]]
+    assert np.abs(dev['points'][:, :3] - X_true).max() < 1e-4
