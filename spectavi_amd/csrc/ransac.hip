@@ -438,8 +438,11 @@ int ransac_fit_run(const double *d_x0, const double *d_x1, long long npt, double
   head.found = head.success = head.count = 0;
   head.cand = -1;
   int done = 0;
-  // easy problems succeed within a few tries: start small, grow to the full batch
-  int step = std::min(batch, 256);
+  // easy problems succeed within a few tries: start small -- 256 tries, fewer when a try is expensive
+  // (about 1e8 (camera, correspondence) solves in the first batch, but at least 8 tries) -- and grow
+  // fourfold to the full batch.  With a million correspondences a batch of 174 tries held some fifty
+  // models that pass the gate, each scored in full, when the first of them already ended the search.
+  int step = std::min(batch, (int)std::max<long long>(8, std::min<long long>(256, 100000000ll / (12 * std::max<long long>(npt, 1)))));
   auto draw = [&](int first, int n, int *dst) -> int {
     next_samples(first, n, dst);
     for (size_t i = 0; i < (size_t)n * 7; ++i)
