@@ -283,7 +283,7 @@ def fuzz_seven_point(seed, budget, only_case=None):
                     if max((mc.parallel(F, G) for G in oFs), default=0.0) < 1 - 1e-9:
                         bad = "an F is not an oracle solution"
                 try:
-                    mc.check_seven_point(Fs[i, :k], x[i], xp[i], "fuzz")
+                    mc.check_seven_point(Fs[i, :k], x[i], xp[i], "fuzz", basis=basis[i])
                 except AssertionError as e:
                     bad = str(e)
             if bad:

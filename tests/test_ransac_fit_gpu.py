@@ -48,7 +48,7 @@ def test_seven_point_batch_matches_oracle_and_numpy(oracle, kind, n):
             assert k == len(oFs), (i, k, len(oFs), margin)
         for F in Fs[i, :k]:
             assert max((mc.parallel(F, G) for G in oFs), default=0.0) >= 1 - 1e-9, i
-        mc.check_seven_point(Fs[i, :k], x[i], xp[i], "%s case %d" % (kind, i))
+        mc.check_seven_point(Fs[i, :k], x[i], xp[i], "%s case %d" % (kind, i), basis=basis[i])
         scale = max(1.0, np.abs(mc.seven_point_rows(x[i], xp[i])).max())
         for F in Fs[i, :k]:
             assert mc.epipolar_residual(F, x[i], xp[i]) < 1e-10 * scale * max(1.0, np.abs(F).max())
