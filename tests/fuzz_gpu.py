@@ -279,8 +279,10 @@ def fuzz_seven_point(seed, budget, only_case=None):
             if bad is None and clear and k != len(oFs):
                 bad = "%d roots, oracle %d" % (k, len(oFs))
             if bad is None and clear:
+                # where the reference's cubic is ill-conditioned, the last bit of libm's acos / cos is amplified too
+                tol = 1e-6 if mc.reference_cubic_is_ill_conditioned(basis[i]) else 1e-9
                 for F in Fs[i, :k]:
-                    if max((mc.parallel(F, G) for G in oFs), default=0.0) < 1 - 1e-9:
+                    if max((mc.parallel(F, G) for G in oFs), default=0.0) < 1 - tol:
                         bad = "an F is not an oracle solution"
                 try:
                     mc.check_seven_point(Fs[i, :k], x[i], xp[i], "fuzz", basis=basis[i])

@@ -46,8 +46,9 @@ def test_seven_point_batch_matches_oracle_and_numpy(oracle, kind, n):
         _, margin, lead = mc.numpy_seven_point(x[i], xp[i])
         if margin > 1e-6 and lead > 1e-10:
             assert k == len(oFs), (i, k, len(oFs), margin)
+        tol = 1e-6 if mc.reference_cubic_is_ill_conditioned(basis[i]) else 1e-9  # libm's acos next to +-1 is amplified there
         for F in Fs[i, :k]:
-            assert max((mc.parallel(F, G) for G in oFs), default=0.0) >= 1 - 1e-9, i
+            assert max((mc.parallel(F, G) for G in oFs), default=0.0) >= 1 - tol, i
         mc.check_seven_point(Fs[i, :k], x[i], xp[i], "%s case %d" % (kind, i), basis=basis[i])
         scale = max(1.0, np.abs(mc.seven_point_rows(x[i], xp[i])).max())
         for F in Fs[i, :k]:
