@@ -342,19 +342,70 @@ def fuzz_ransac_fit(seed, budget, only_case=None):
     return n
 
 
+def fuzz_pipeline(seed, budget, only_case=None):
+    """Steps 2-4 of the reference's example on random synthetic SIFT table pairs: the device-resident
+    pipeline (every intermediate in HBM) against the same steps through the host front-end -- same
+    matches, and with the same RANSAC seed the same model, inliers and triangulated points to rounding --
+    and both against the scene (true pairs, essential matrix)."""
+    import torch
+    from examples import essential_from_sift_tables as ex
+    t0, n = time.time(), 0 if only_case is None else only_case
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng([seed, 8, n])
+        nc = int(rng.choice([60, 200, 1000, rng.integers(60, 4000)]))
+        ne = int(rng.choice([0, 10, nc // 2, nc]))
+        wrong = float(rng.choice([0.0, 0.1, 0.3]))
+        ta, tb, K, truth = ex.synthetic_sift_pair(int(rng.integers(0, 1 << 30)), nc, ne, wrong_fraction=wrong)
+        rs = int(rng.integers(1, 1 << 30))
+        os.environ["SPECTAVI_RANSAC_SEED"] = str(rs)
+        host = ex.host_pipeline(ta, tb, K, descriptor_only=True, maximum_tries=20000)
+        dev = ex.device_pipeline(torch.from_numpy(ta).cuda(), torch.from_numpy(tb).cuda(), K, maximum_tries=20000, seed=rs)
+        ok = np.array_equal(host['matches'], dev['matches']) and host['ransac']['success'] == dev['ransac']['success']
+        if ok and dev['ransac']['success']:
+            # the calibration x K^-T is a numpy product on one side and a torch matmul on the other: the
+            # correspondences may differ in the last bit, hence F too, hence (two equal singular values of E)
+            # the sign of the camera; everything is compared to rounding, the camera up to its sign
+            hP, dP = host['ransac']['camera'], dev['ransac']['camera']
+            ok = (np.allclose(host['ransac']['essential'], dev['ransac']['essential'], rtol=1e-7, atol=1e-12) and
+                  min(np.abs(hP - dP).max(), np.abs(hP + dP).max()) < 1e-7 and
+                  np.array_equal(host['ransac']['inlier_idx'][:, 0], dev['ransac']['inlier_idx']) and
+                  np.allclose(host['points'], dev['points'], rtol=1e-7, atol=1e-9))
+            m = dev['matches']
+            good = (truth['true_row0'][m[:, 0]] == m[:, 1]) & truth['consistent'][m[:, 0]]
+            # against the scene: the true consistent pairs are inliers (a wrongly placed keypoint may satisfy the
+            # epipolar constraint by chance: a few extras are allowed), E is the scene's up to scale
+            inl = dev['ransac']['inlier_idx']
+            missed, extra = np.setdiff1d(np.flatnonzero(good), inl), np.setdiff1d(inl, np.flatnonzero(good))
+            from tests import mvg_checks as mc
+            par = mc.parallel(dev['ransac']['essential'], truth['E'])
+            if ok and not (len(missed) <= 0.3 * good.sum() and len(extra) <= 3 + 0.01 * len(m) and par >= 1 - 1e-3):  # the search stops at 70 % inliers  # one minimal sample on float32 pixel coordinates, no refit
+                raise SystemExit("PIPELINE vs SCENE case=%d common=%d extra=%d wrong=%g ransac seed %d: missed %d extra %d of %d, "
+                                 "1 - cos(E, E_true) = %.2e" % (n, nc, ne, wrong, rs, len(missed), len(extra), good.sum(), 1 - par))
+        if not ok:
+            raise SystemExit("PIPELINE MISMATCH (device-resident vs host front-end) case=%d common=%d extra=%d wrong=%g ransac seed %d" %
+                             (n, nc, ne, wrong, rs))
+        n += 1
+        if only_case is not None:
+            break
+    return n
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0, help="budget per path")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma list of l1k2,cascade,dlt,ratio,score,normalize,seven_point,ransac_fit")
+    ap.add_argument("--only", default="", help="comma list of l1k2,cascade,dlt,ratio,score,normalize,seven_point,ransac_fit,pipeline")
     ap.add_argument("--case", type=int, default=None, help="re-run one case number of the --only path")
     a = ap.parse_args()
     want = set(filter(None, a.only.split(",")))
     for name, fn in (("l1k2", fuzz_l1k2), ("cascade", fuzz_cascade), ("dlt", fuzz_dlt), ("ratio", fuzz_ratio),
                      ("score", fuzz_score), ("normalize", fuzz_normalize), ("seven_point", fuzz_seven_point),
-                     ("ransac_fit", fuzz_ransac_fit)):
+                     ("ransac_fit", fuzz_ransac_fit), ("pipeline", fuzz_pipeline)):
         if want and name not in want:
             continue
         cases = fn(a.seed, a.seconds, a.case)
+        if name == "pipeline":
+            print("pipeline: %d random scenes, device-resident == host front-end (to rounding), both consistent with the scene" % cases, flush=True)
+            continue
         print("%s: %d random cases %s the oracle" % (name, cases, "agree with" if name in ("seven_point", "ransac_fit")
                                                        else "bit-identical to"), flush=True)

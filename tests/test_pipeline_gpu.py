@@ -78,11 +78,14 @@ def test_example_pipeline_device_resident_equals_host_and_oracle(oracle, monkeyp
     _check_against_truth(host, truth, t1)
     _check_against_truth(dev, truth, t1)
     assert np.array_equal(host['matches'], dev['matches'])
-    # same seed, same correspondences: the same subsets, hence the same model, bit for bit
-    assert np.array_equal(host['ransac']['essential'], dev['ransac']['essential'])
-    assert np.array_equal(host['ransac']['camera'], dev['ransac']['camera'])
+    # same seed, same subsets, hence the same model -- to rounding: the calibration x K^-T is a numpy
+    # product on one side and a torch matmul on the other, so the correspondences may differ in the last
+    # bit, F with them, and (E has two equal singular values) the camera in its sign
+    assert np.allclose(host['ransac']['essential'], dev['ransac']['essential'], rtol=1e-7, atol=1e-12)
+    hP, dP = host['ransac']['camera'], dev['ransac']['camera']
+    assert min(np.abs(hP - dP).max(), np.abs(hP + dP).max()) < 1e-7
     assert np.array_equal(host['ransac']['inlier_idx'][:, 0], dev['ransac']['inlier_idx'])
-    assert np.array_equal(host['points'], dev['points'])
+    assert np.allclose(host['points'], dev['points'], rtol=1e-7, atol=1e-9)
     # the CPU oracle on the same subsets
     om, ofit, oX, x0, x1 = _oracle_pipeline(oracle, t0, t1, K, lambda n: mvg.ransac_sample(11, n, dev['ransac']['tries_run']),
                                             descriptor_only=True)
