@@ -117,7 +117,8 @@ size_t dlt_score_workspace_bytes(int nhyp, long long npt);
 // listed in d_live (device memory); the counts of the others stay 0, their mask rows unwritten
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask, void *d_ws,
-                  size_t ws_bytes, hipStream_t stream, const int *d_live = nullptr, const int *d_nlive = nullptr);
+                  size_t ws_bytes, hipStream_t stream, const int *d_live = nullptr, const int *d_nlive = nullptr,
+                  int rows_cap = 65535);
 
 
 // ---- RANSAC candidate processing (dlt.hip): gate, E, four cameras, scoring, best camera ----
@@ -126,7 +127,8 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
                        double ratio_allowed, double required_percent, double max_error, int find_best,
                        int *d_success, int *d_inlier_count, int *d_best_cam, double *d_best_P, double *d_ratio,
                        double *d_E, int *d_counts4, unsigned char *d_mask, void *d_ws, size_t ws_bytes,
-                       hipStream_t stream);
+                       hipStream_t stream, int score_rows_cap = 65535);  // grid rows of the scorer: a RANSAC batch, whose
+                                                                          // candidates are nearly all gated, passes 2048
 
 // ---- seven-point solver and the RANSAC loop around the candidate processing (ransac.hip) ----
 // d_x, d_xp double[n,7,2] euclidean; d_Fs double[n,3,9] (NaN in the slots of missing roots);

@@ -365,7 +365,7 @@ struct WorkList {
 
 // cand / ncand (RANSAC candidate processing): the candidates that passed the gate, in any order;
 // row y then scores camera y % 4 of candidate cand[y / 4], and the grid has only as many rows
-// (at most 2 048, each workgroup walking y, y + gridDim.y, ...) as a batch plausibly needs: almost
+// (the caller's cap -- 2 048 for a RANSAC batch --, each workgroup walking y, y + gridDim.y, ...) as a batch plausibly needs: almost
 // every candidate of a RANSAC batch is gated, and a grid row per gated camera is a row of workgroups
 // that start only to find a NaN and leave -- 500 000 of them per batch of 5 461 tries, 1.2 of the
 // batch's 2 ms in launch rate alone.  Without a list row y is hypothesis y.
@@ -764,7 +764,7 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
                        double ratio_allowed, double required_percent, double max_error, int find_best,
                        int *d_success, int *d_inlier_count, int *d_best_cam, double *d_best_P, double *d_ratio,
                        double *d_E, int *d_counts4, unsigned char *d_mask, void *d_ws, size_t ws_bytes,
-                       hipStream_t stream) {
+                       hipStream_t stream, int score_rows_cap) {
   if (nF < 0 || npt < 0) return set_error(SPV_ERR_INVALID, "negative count");
   if (nF == 0) return SPV_OK;
   if (!d_Fs || !d_success || !d_inlier_count || !d_best_cam || (npt > 0 && (!d_x0 || !d_x1)))
@@ -796,7 +796,8 @@ int ransac_process_run(const double *d_Fs, int nF, long long npt, const double *
   }
   const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // Camera(): Identity(3,4), src/Camera.h:27
   // a mask row of a gated camera is never looked at (best_mask_kernel only reads the best camera's)
-  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, ws, score_ws, stream, live, nlive));
+  SPV_TRY(dlt_score_run(P0, cams, 4 * nF, npt, d_x0, d_x1, max_error, counts, mask4, ws, score_ws, stream, live, nlive,
+                        score_rows_cap));
   hipLaunchKernelGGL(select_camera_kernel, dim3(fblocks), dim3(kDltThreads), 0, stream, counts, gated, cams, nF, npt,
                      required_percent, find_best, d_success, d_inlier_count, d_best_cam, d_best_P, d_counts4);
   SPV_HIP_CHECK(hipGetLastError());
@@ -825,7 +826,7 @@ size_t dlt_score_workspace_bytes(int nhyp, long long npt) {
 
 int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt, const double *d_x,
                   const double *d_xp, double max_error, int *d_counts, unsigned char *d_mask, void *d_ws,
-                  size_t ws_bytes, hipStream_t stream, const int *d_live, const int *d_nlive) {
+                  size_t ws_bytes, hipStream_t stream, const int *d_live, const int *d_nlive, int rows_cap) {
   if (npt < 0 || nhyp < 0) return set_error(SPV_ERR_INVALID, "negative count");
   if (!P0) return set_error(SPV_ERR_INVALID, "null camera pointer");
   if (nhyp == 0) return SPV_OK;
@@ -840,7 +841,7 @@ int dlt_score_run(const double *P0, const double *d_p1s, int nhyp, long long npt
   const long long blocks = (npt + kDltThreads - 1) / kDltThreads;
   if (blocks > 0x7FFFFFFFLL) return set_error(SPV_ERR_INVALID, "too many points");
   ProfScope prof("dlt_score", stream);
-  const dim3 grid((unsigned)blocks, (unsigned)(d_live ? std::min(nhyp, 2048) : nhyp));
+  const dim3 grid((unsigned)blocks, (unsigned)(d_live ? std::min(nhyp, std::max(rows_cap, 4)) : nhyp));
   // a workspace too small for the work list is not an error: the scorer then runs in one pass
   WorkList wl{nullptr, nullptr, 0};
   if (d_ws && ws_bytes > kScoreCountBytes && (reinterpret_cast<uintptr_t>(d_ws) & 7) == 0) {

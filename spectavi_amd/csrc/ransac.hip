@@ -461,7 +461,8 @@ int ransac_fit_run(const double *d_x0, const double *d_x1, long long npt, double
       SPV_HIP_CHECK(hipGetLastError());
     }
     SPV_TRY(ransac_process_run(b.Fs, 3 * n, npt, d_x0, d_x1, ratio_allowed, required_percent, max_error, find_best, b.ok,
-                               b.count, b.best_cam, b.best_P, nullptr, nullptr, nullptr, nullptr, b.ws, b.ws_bytes, stream));
+                               b.count, b.best_cam, b.best_P, nullptr, nullptr, nullptr, nullptr, b.ws, b.ws_bytes, stream,
+                               2048));
     {
       ProfScope prof("ransac_reduce", stream);
       hipLaunchKernelGGL(ransac_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, (const int *)b.ok,
