@@ -366,10 +366,12 @@ def fuzz_pipeline(seed, budget, only_case=None):
             # correspondences may differ in the last bit, hence F too, hence (two equal singular values of E)
             # the sign of the camera; everything is compared to rounding, the camera up to its sign
             hP, dP = host['ransac']['camera'], dev['ransac']['camera']
-            ok = (np.allclose(host['ransac']['essential'], dev['ransac']['essential'], rtol=1e-7, atol=1e-12) and
-                  min(np.abs(hP - dP).max(), np.abs(hP + dP).max()) < 1e-7 and
+            # (a minimal solver amplifies a last-bit difference of its seven correspondences by up to ~1e8)
+            hF, dF = host['ransac']['essential'], dev['ransac']['essential']
+            ok = (np.abs(hF - dF).max() <= 1e-6 * np.abs(hF).max() and
+                  min(np.abs(hP - dP).max(), np.abs(hP + dP).max()) < 1e-6 and
                   np.array_equal(host['ransac']['inlier_idx'][:, 0], dev['ransac']['inlier_idx']) and
-                  np.allclose(host['points'], dev['points'], rtol=1e-7, atol=1e-9))
+                  np.allclose(host['points'], dev['points'], rtol=1e-5, atol=1e-6))
             m = dev['matches']
             good = (truth['true_row0'][m[:, 0]] == m[:, 1]) & truth['consistent'][m[:, 0]]
             # against the scene: the true consistent pairs are inliers (a wrongly placed keypoint may satisfy the
