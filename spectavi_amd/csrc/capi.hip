@@ -958,6 +958,7 @@ int check_fit_args(const double *x0, const double *x1, int npt, int max_tries) {
   // RansacFitter's constructor, src/RansacFitter.h:146-149
   if (npt < 10) return set_error(SPV_ERR_INVALID, "Supplied less than 10 point matches, unsupported.");
   if (max_tries < 0) return set_error(SPV_ERR_INVALID, "negative maximum_tries");
+  if (max_tries > 700000000) return set_error(SPV_ERR_INVALID, "maximum_tries above 7e8 (candidate ids are 32-bit: 3 per try)");
   return SPV_OK;
 }
 

@@ -247,3 +247,20 @@ def test_ransac_sample_is_the_reference_draw():
         assert not np.array_equal(s, mvg.ransac_sample(6, npt, 400))
     with pytest.raises(Exception):
         mvg.ransac_sample(1, 9, 1)
+
+
+def test_ransac_fit_argument_checks_without_gpu():
+    """Argument checks of the RANSAC entry points happen before any device is touched."""
+    from spectavi_amd import mvg
+    from spectavi_amd._lib import SPV_ERR_INVALID
+    x = np.zeros((12, 3))
+    ok, n = ct.c_int32(0), ct.c_int32(0)
+    pct = ct.c_double(0)
+    F, P, idx = np.zeros(9), np.zeros(12), np.zeros(12, np.int32)
+
+    def call(npt, tries):
+        return mvg._spv_ransac_fit(x, x, npt, .9, .5, tries, 1, 3e-2, 1, ct.byref(ok), F, P, ct.byref(pct), idx, ct.byref(n),
+                                   None, None, None)
+    assert call(9, 10) == SPV_ERR_INVALID        # fewer than 10 correspondences (the reference's constructor throws)
+    assert call(12, -1) == SPV_ERR_INVALID
+    assert call(12, 800000000) == SPV_ERR_INVALID
