@@ -41,7 +41,31 @@ def dlt(npt=1_000_000):
             "points": npt, "threads": 1, "seconds": dt, "points_per_s": npt / dt}
 
 
+def ransac():
+    """The oracle's serial RANSAC loop (reference fit_essential with nthread = 1) on the scenes of
+    tools/bench_paths.py --only fit: tries/s with no try succeeding (a try costs microseconds when the
+    gate rejects its candidates, 4 x npt SVDs per candidate when not)."""
+    from tests import mvg_checks as mc
+    rng = np.random.default_rng(21)
+    for npt in (500, 2000, 20000):
+        x0, x1, E, out_idx = mc.two_view_scene(rng, npt=npt, outlier_fraction=0.4, noise=1e-4)
+        tries = 2000 if npt <= 2000 else 400
+        srng = np.random.default_rng(2)
+        samples = np.stack([srng.choice(np.arange(1, npt), 7, replace=False) for _ in range(tries)]).astype(np.int32)
+        t0 = time.perf_counter()
+        o.ransac_fit(x0, x1, samples, required_percent_inliers=0.999, reprojection_error_allowed=1e-3,
+                     singular_value_ratio_allowed=3e-2)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"path": "ransac_fit (serial loop of oracle_ransac.cpp: seven-point + process_fundamental_matrix "
+                                  "per root, reference src/RansacFitter.h:152-272 with nthread = 1)",
+                          "correspondences": npt, "outliers": 0.4, "tries": tries, "threads": 1, "seconds": dt,
+                          "tries_per_s": tries / dt}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ransac":
+        ransac()
+        sys.exit(0)
     allc = o.max_threads()
     cpu = [l for l in open("/proc/cpuinfo") if l.startswith("model name")]
     print(json.dumps({"cpu": cpu[0].split(":", 1)[1].strip() if cpu else "?", "logical_cpus": os.cpu_count(),

@@ -312,7 +312,7 @@ def next_rows(steps, warmup):
 def ransac_fit():
     """The RANSAC loop itself (seven-point solve + candidate processing + best-model rule) through the
     host-pointer entry: all tries evaluated (requirement out of reach) for the rate, then the time to
-    the first success on the same scene; the oracle's serial loop timed beside it on a few tries."""
+    the first success on the same scene.  (The CPU side of this line is tests/cpu_baseline.py ransac.)"""
     from spectavi_amd import mvg
     from tests import mvg_checks as mc
     rng = np.random.default_rng(21)
@@ -335,19 +335,12 @@ def ransac_fit():
             rs = mvg.ransac_fit(x0, x1, required_percent_inliers=0.5, maximum_tries=tries, seed=seed, **kw)
             t_succ.append(time.perf_counter() - t0)
             n_succ.append(rs["tries_run"] if rs["success"] else -1)
-        from oracle import oracle as o
-        cpu_tries = 2000 if npt <= 2000 else 400  # a try costs microseconds when the gate rejects it, 4 x npt SVDs when not
-        samples = mvg.ransac_sample(2, npt, cpu_tries)
-        t0 = time.perf_counter()
-        o.ransac_fit(x0, x1, samples, required_percent_inliers=0.999, **kw)
-        cpu_dt = time.perf_counter() - t0
         print(json.dumps({"metric": "RANSAC fit (7-subset -> seven-point -> 3 candidates x 4 cameras x all correspondences -> best model), tries/s",
                           "value": tries / dt, "unit": "tries/s", "ms_total": dt * 1e3, "kernel_ms": parts,
                           "config": {"workload": "%d correspondences, 40 %% outliers, %d tries, none succeeds" % (npt, tries)},
                           "first_success": {"required_percent_inliers": 0.5, "ms": [round(t * 1e3, 2) for t in t_succ],
                                             "tries_run": n_succ},
-                          "cpu_baseline": {"value": cpu_tries / cpu_dt, "unit": "tries/s", "cores": 1, "kind": "port",
-                                           "sample": "%d tries of the same scene, serial loop of oracle_ransac.cpp" % cpu_tries},
+                          "cpu_baseline": "tests/cpu_baseline.py ransac (the oracle's serial loop on the same scenes)",
                           "dtype": "f64", "data": "synthetic"}), flush=True)
 
 
