@@ -320,6 +320,24 @@ int spv_l1k2_device(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows
                     uint64_t *d_idx, int32_t *d_dist, void *d_ws, size_t ws_bytes,
                     void *stream);
 
+/* The query loop sharded over the GPUs of one node with everything resident (the loop
+ * the reference shards over OpenMP threads, src/BruteForceNnL1K2.h:92-93): one process, rank r =
+ * devices[r].  d_x[r] is that device's replica of the database uint8[xrows,dim]; d_y[r] its query
+ * shard uint8[spv_shard_lo(total, ndev, r + 1) - spv_shard_lo(total, ndev, r), dim] (contiguous
+ * balanced shards of the yrows_total queries, the first total % ndev one row longer).  Every device
+ * runs the L1 kernels on its shard and packs (idx0, idx1, d0, d1) into 16-byte records; the records
+ * are gathered on devices[0] -- transport SPV_GATHER_RCCL: ncclGather on a cached ncclCommInitAll
+ * clique (distinct devices), SPV_GATHER_PEERCOPY: one hipMemcpyPeerAsync per rank -- and widened
+ * there into d_idx uint64[yrows_total,2], d_dist int32[yrows_total,2] (memory of devices[0]).
+ * Synchronous: returns after all ranks' streams have drained; the caller's buffers must be ready
+ * (its own streams synchronised) on entry.  Scratch comes from the library's per-device cache.
+ * spv_profile_read("gather") / ("gather_widen") time the exchange. */
+int spv_l1k2_gathered_device(int ndev, const int *devices, const uint8_t *const *d_x,
+                             const uint8_t *const *d_y, int xrows, long long yrows_total, int dim,
+                             uint64_t *d_idx, int32_t *d_dist, int transport);
+/* First row of shard r of `total` rows over `shards` contiguous balanced shards (r = shards: total). */
+long long spv_shard_lo(long long total, int shards, int r);
+
 /* Scratch bytes needed by spv_cascade_device. */
 size_t spv_cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, int g);
 /* d_x,d_y float32[rows,dim]; d_dict float32[n,dim,m]; outputs as in section 2

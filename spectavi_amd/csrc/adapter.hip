@@ -240,6 +240,7 @@ constexpr int kFoldTile = 256;     // rows staged per step
 constexpr int kFoldCols = 16;      // columns per workgroup: one 64-byte sector of every row
 constexpr int kFoldThreads = 256;
 constexpr int kFoldStride = kFoldCols + 1;
+static_assert(kFoldCols == kStatCols, "normalize_run sizes one column-block grid and `blockserial` for both the statistics and the fold kernels");
 constexpr int kNoGuess = -1000;
 
 struct FoldBufs {

@@ -201,7 +201,29 @@ static std::vector<int> device_list() {
 // into its slice (direct), or gathered on the first listed GPU over RCCL and copied from there
 // (north_star's "RCCL gather of (idx0, idx1, d0, d1)").  spv_set_gather_mode / SPECTAVI_GATHER
 // choose; left alone, RCCL is used exactly when more than one distinct device is configured.
-static int gather_transport(const std::vector<int> &devs) {
+// Automatic mode only: can a clique over exactly these devices be built?  (librccl opened,
+// ncclCommInitAll done; both cached, a refusal too, so a box without a usable RCCL pays once.)
+static bool rccl_clique_usable(const std::vector<int> &devs) {
+  static std::mutex mu;
+  static std::map<std::vector<int>, bool> known;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = known.find(devs);
+  if (it != known.end()) return it->second;
+  bool ok;
+  {
+    std::lock_guard<std::mutex> glk(gather_mutex());
+    GatherCtx *ctx = nullptr;
+    ok = gather_ctx_get(devs, true, &ctx) == SPV_OK;
+  }
+  if (!ok) {
+    fprintf(stderr, "libspectavi: RCCL gather unavailable (%s); sharding with direct copies instead\n", g_message);
+    clear_error();
+  }
+  known[devs] = ok;
+  return ok;
+}
+
+static int gather_transport(const std::vector<int> &devs, long long total = -1) {
   int mode;
   {
     std::lock_guard<std::mutex> lk(g_cfg_mutex);
@@ -213,14 +235,17 @@ static int gather_transport(const std::vector<int> &devs) {
     if (e && !strcmp(e, "direct")) mode = SPV_GATHER_DIRECT;
     if (e && !strcmp(e, "copy")) mode = SPV_GATHER_PEERCOPY;
   }
-  if (mode >= 0) return mode;
+  if (mode >= 0) return mode;  // asked for by name: a failure of that transport is the caller's error
   if (devs.size() < 2) return SPV_GATHER_DIRECT;
   for (size_t a = 0; a < devs.size(); ++a)
     for (size_t b = a + 1; b < devs.size(); ++b)
       if (devs[a] == devs[b]) return SPV_GATHER_DIRECT;  // a clique needs distinct devices
+  // the clique a call of `total` rows would use (run_gathered lists no more ranks than rows)
+  const size_t G = total < 0 ? devs.size() : (size_t)std::min<long long>((long long)devs.size(), std::max<long long>(total, 1));
+  if (!rccl_clique_usable(std::vector<int>(devs.begin(), devs.begin() + G))) return SPV_GATHER_DIRECT;
   return SPV_GATHER_RCCL;
 }
-static bool use_rccl_gather(const std::vector<int> &devs) { return gather_transport(devs) != SPV_GATHER_DIRECT; }
+static bool use_rccl_gather(const std::vector<int> &devs, long long total) { return gather_transport(devs, total) != SPV_GATHER_DIRECT; }
 
 int ensure_device() { return use_device(device_list()[0]); }
 
@@ -375,6 +400,10 @@ struct DevBuf {
 // writing to it early is allowed.  Skipped when the output overlaps an input.
 class HostPrefault {
  public:
+  // Pages are touched in 2 MB blocks dealt round-robin to the threads (block j belongs to thread
+  // j % T), so the front of the array is ready first and wait_range() can release a consumer
+  // that only needs a prefix while the rest is still being touched.
+  static constexpr size_t kBlock = (size_t)2 << 20;
   HostPrefault(void *dst, size_t bytes, std::initializer_list<std::pair<const void *, size_t>> inputs) {
     constexpr size_t kMin = (size_t)16 << 20, kPage = 4096;
     if (!dst || bytes < kMin) return;
@@ -385,14 +414,37 @@ class HostPrefault {
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int T = (int)std::min<size_t>(std::min<unsigned>(8u, hw), bytes / kMin + 1);
-    const size_t per = round_up((bytes + T - 1) / T, kPage);
+    const size_t nblocks = (bytes + kBlock - 1) / kBlock;
+    done_.reset(new std::atomic<size_t>[T]);
+    for (int i = 0; i < T; ++i) done_[i].store(0, std::memory_order_relaxed);
+    nthreads_ = T;
     try {
       for (int i = 0; i < T; ++i)
         threads_.emplace_back([=] {
           volatile char *p = static_cast<volatile char *>(dst);
-          for (size_t off = per * i; off < std::min(bytes, per * (i + 1)); off += kPage) p[off] = 0;
+          size_t mine = 0;
+          for (size_t b = (size_t)i; b < nblocks; b += (size_t)T) {
+            for (size_t off = b * kBlock; off < std::min(bytes, (b + 1) * kBlock); off += kPage) p[off] = 0;
+            done_[i].store(++mine, std::memory_order_release);
+          }
+          done_[i].store(SIZE_MAX, std::memory_order_release);
         });
     } catch (...) {  // could not start a thread: the copy simply faults the pages itself
+    }
+    // a thread that never started owns blocks nobody touches: they count as done (the copy into
+    // them then faults the pages itself, which is only slower)
+    for (int i = (int)threads_.size(); i < T; ++i) done_[i].store(SIZE_MAX, std::memory_order_release);
+  }
+  // Returns once no prefault store can land in [off, off + len) any more: a consumer must call
+  // this (or wait()) before it writes real data there -- a late `p[off] = 0` would otherwise
+  // overwrite one byte per page of the result.
+  void wait_range(size_t off, size_t len) {
+    if (nthreads_ == 0 || len == 0) return;
+    const size_t b0 = off / kBlock, b1 = (off + len - 1) / kBlock;
+    for (size_t b = b0; b <= b1; ++b) {
+      const int owner = (int)(b % (size_t)nthreads_);
+      const size_t need = b / (size_t)nthreads_ + 1;  // blocks the owner must have finished
+      while (done_[owner].load(std::memory_order_acquire) < need) std::this_thread::yield();
     }
   }
   void wait() {
@@ -404,6 +456,8 @@ class HostPrefault {
 
  private:
   std::vector<std::thread> threads_;
+  std::unique_ptr<std::atomic<size_t>[]> done_;
+  int nthreads_ = 0;
 };
 
 // ---- results back to pageable host memory ------------------------------------------------
@@ -483,6 +537,9 @@ class D2HPipeline {
     }
     started_ = (int)threads_.size();
   }
+  // The caller's array is still being pre-touched by `touch`: every slice waits for its own pages
+  // before the pinned -> caller copy (call before the first ready(); touch must outlive finish()).
+  void set_prefault(HostPrefault *touch) { prefault_ = touch; }
   // chunk k (bytes [k * chunk, (k+1) * chunk) of the source) is final once `ev` has passed;
   // chunks must be announced in order.  ev must outlive finish().
   void ready(int k, hipEvent_t ev) {
@@ -545,6 +602,7 @@ class D2HPipeline {
         ok = false;
         fail(SPV_ERR_HIP, "device-to-host copy", e);
       } else {
+        if (prefault_) prefault_->wait_range(prev_off, prev_len);
         memcpy(dst_ + prev_off, pin[prev_slot], prev_len);
       }
       prev_slot = -1;
@@ -598,6 +656,7 @@ class D2HPipeline {
   std::vector<hipEvent_t> events_;
   int workers_ = 1, started_ = 0;
   size_t piece_ = 0;
+  HostPrefault *prefault_ = nullptr;
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_;
@@ -688,7 +747,7 @@ int host_l1k2(const uint8_t *x, const uint8_t *y, int xrows, int yrows, int dim,
               int32_t *dist) {
   if (yrows < 0) return set_error(SPV_ERR_INVALID, "negative row count");
   const std::vector<int> devs = device_list();
-  if (yrows > 0 && use_rccl_gather(devs)) return host_l1k2_gathered(devs, x, y, xrows, yrows, dim, idx, dist);
+  if (yrows > 0 && use_rccl_gather(devs, yrows)) return host_l1k2_gathered(devs, x, y, xrows, yrows, dim, idx, dist);
   return run_sharded(yrows, [&](int dev, long long lo, long long hi) {
     return host_l1k2_one(dev, x, y ? y + (size_t)lo * dim : y, xrows, (int)(hi - lo), dim,
                          idx ? idx + 2 * lo : idx, dist ? dist + 2 * lo : dist);
@@ -745,7 +804,7 @@ int host_cascade(const float *x, const float *y, int xrows, int yrows, int dim, 
                  int g, const float *dict, uint64_t *idx, float *dist, int32_t *ncand) {
   SPV_TRY(check_cascade_args(xrows, yrows, dim, m, n, g));
   const std::vector<int> devs = device_list();
-  if (yrows > 0 && use_rccl_gather(devs))
+  if (yrows > 0 && use_rccl_gather(devs, yrows))
     return host_cascade_gathered(devs, x, y, xrows, yrows, dim, m, n, g, dict, idx, dist, ncand);
   return run_sharded(yrows, [&](int dev, long long lo, long long hi) {
     return host_cascade_one(dev, x, y ? y + (size_t)lo * dim : y, xrows, (int)(hi - lo), dim, m, n, g,
@@ -788,6 +847,7 @@ int host_dlt_one(int dev, const double *P0, const double *P1, int npt, const dou
   std::vector<ScopedEvent> produced(nchunks);
   HostPrefault touch(dst, ob, {{x, ib}, {xp, ib}});
   D2HPipeline pipe(dev, dd.p, dst, ob, (size_t)chunk_pts * row);
+  pipe.set_prefault(&touch);  // a slice lands only after its own pages have been touched
   int status = SPV_OK;
   for (int k = 0; k < nchunks && status == SPV_OK; ++k) {
     const long long p0 = (long long)k * chunk_pts, cnt = std::min<long long>(chunk_pts, npt - p0);
@@ -818,7 +878,7 @@ int host_dlt(const double *P0, const double *P1, int npt, const double *x, const
   if (npt < 0) return set_error(SPV_ERR_INVALID, "negative point count");
   const int cols = want_error ? 1 : 4;
   const std::vector<int> devs = device_list();
-  if (npt > 0 && use_rccl_gather(devs)) return host_dlt_gathered(devs, P0, P1, npt, x, xp, dst, want_error);
+  if (npt > 0 && use_rccl_gather(devs, npt)) return host_dlt_gathered(devs, P0, P1, npt, x, xp, dst, want_error);
   return run_sharded(npt, [&](int dev, long long lo, long long hi) {
     return host_dlt_one(dev, P0, P1, (int)(hi - lo), x ? x + 3 * lo : x, xp ? xp + 3 * lo : xp,
                         dst ? dst + cols * lo : dst, want_error);
@@ -1106,14 +1166,14 @@ struct BufList {
 // [G][max_cnt] rows in rank order.  Everything is synchronised before the buffers are released.
 template <typename Produce, typename Consume>
 int run_gathered(const std::vector<int> &all_devs, long long total, const std::vector<size_t> &row_bytes,
-                 Produce produce, Consume consume) {
+                 Produce produce, Consume consume, int transport = SPV_GATHER_AUTO) {
   const int G = (int)std::min<long long>((long long)all_devs.size(), std::max<long long>(total, 1));
   const std::vector<int> devs(all_devs.begin(), all_devs.begin() + G);
   const size_t K = row_bytes.size();
   std::lock_guard<std::mutex> lk(gather_mutex());  // one clique user at a time
   for (int d : devs) SPV_TRY(use_device(d));         // fail early on a bad device number
   GatherCtx *ctx = nullptr;
-  SPV_TRY(gather_ctx_get(devs, gather_transport(all_devs) == SPV_GATHER_RCCL, &ctx));
+  SPV_TRY(gather_ctx_get(devs, (transport == SPV_GATHER_AUTO ? gather_transport(all_devs, total) : transport) == SPV_GATHER_RCCL, &ctx));
   const long long max_cnt = shard_lo(total, G, 1);   // = size of shard 0, the largest
   std::vector<BufList> bufs(G + 1);                  // [G] = the root's receive / staging buffers
   std::vector<std::vector<const void *>> send(K, std::vector<const void *>(G, nullptr));
@@ -1204,6 +1264,32 @@ int host_l1k2_gathered(const std::vector<int> &devs, const uint8_t *x, const uin
     return SPV_OK;
   };
   return run_gathered(devs, yrows, {sizeof(Record)}, produce, consume);
+}
+
+// The same exchange with everything resident: device devs[r] already holds a replica of the database
+// (d_x[r]) and its contiguous balanced query shard (d_y[r]); the widened result lands in d_idx /
+// d_dist on devs[0].  Scratch comes from the per-device buffer cache, so repeated calls allocate
+// nothing.  Returns after every rank's stream has drained.
+int device_l1k2_gathered(const std::vector<int> &devs, const uint8_t *const *d_x, const uint8_t *const *d_y,
+                         int xrows, long long yrows, int dim, uint64_t *d_idx, int32_t *d_dist, int transport) {
+  auto produce = [&](int r, long long lo, long long hi, long long max_cnt, hipStream_t st, BufList &b,
+                     std::vector<const void *> &send) {
+    const int cnt = (int)(hi - lo);
+    const size_t wsb = spv_l1k2_workspace_bytes(xrows, cnt, dim);
+    DevBuf *di, *dd, *ws, *rec;
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(uint64_t), &di));
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(int32_t), &dd));
+    SPV_TRY(b.add(wsb, &ws));
+    SPV_TRY(b.add((size_t)max_cnt * sizeof(Record), &rec));
+    SPV_TRY(l1k2_run(d_x[r], d_y[r], xrows, cnt, dim, di->as<uint64_t>(), dd->as<int32_t>(), ws->p, wsb, st));
+    SPV_TRY(gather_pack_run(di->as<uint64_t>(), dd->p, cnt, rec->p, st));
+    send[0] = rec->p;
+    return SPV_OK;
+  };
+  auto consume = [&](const std::vector<const void *> &recv, int G, long long max_cnt, hipStream_t st, BufList &) {
+    return gather_widen_run(recv[0], yrows, G, max_cnt, d_idx, d_dist, st);
+  };
+  return run_gathered(devs, yrows, {sizeof(Record)}, produce, consume, transport);
 }
 
 int host_cascade_gathered(const std::vector<int> &devs, const float *x, const float *y, int xrows, int yrows,
@@ -1755,6 +1841,38 @@ size_t spv_cascade_workspace_bytes(int xrows, int yrows, int dim, int m, int n, 
       yrows < 0)
     return 0;
   return cascade_workspace_bytes(xrows, yrows, dim, m, n, g);
+}
+
+int spv_l1k2_gathered_device(int ndev, const int *devices, const uint8_t *const *d_x, const uint8_t *const *d_y,
+                             int xrows, long long yrows_total, int dim, uint64_t *d_idx, int32_t *d_dist,
+                             int transport) {
+  clear_error();
+  return host_guard([&] {
+    if (ndev < 1 || ndev > 64 || !devices || !d_x || !d_y) return set_error(SPV_ERR_INVALID, "bad device list");
+    if (transport != SPV_GATHER_RCCL && transport != SPV_GATHER_PEERCOPY)
+      return set_error(SPV_ERR_INVALID, "transport must be SPV_GATHER_RCCL or SPV_GATHER_PEERCOPY");
+    if (xrows < 0 || yrows_total < 0 || yrows_total > (long long)INT32_MAX * ndev)
+      return set_error(SPV_ERR_INVALID, "bad row count");
+    if (dim <= 0 || dim % 16 != 0)
+      return set_error(SPV_ERR_INVALID, "Input matrix inner dimensions must be 16-byte aligned (dim=%d).", dim);
+    if (yrows_total == 0) return (int)SPV_OK;
+    if (!d_idx || !d_dist) return set_error(SPV_ERR_INVALID, "null pointer");
+    const std::vector<int> devs(devices, devices + ndev);
+    const int G = (int)std::min<long long>(ndev, yrows_total);
+    for (int r = 0; r < G; ++r) {
+      if (!d_y[r] || (xrows > 0 && !d_x[r])) return set_error(SPV_ERR_INVALID, "null pointer (rank %d)", r);
+      if (((uintptr_t)d_y[r] | (uintptr_t)d_x[r]) & 15)
+        return set_error(SPV_ERR_INVALID, "device pointers must be 16-byte aligned (rank %d)", r);
+    }
+    if (((uintptr_t)d_idx | (uintptr_t)d_dist) & 15) return set_error(SPV_ERR_INVALID, "device pointers must be 16-byte aligned");
+    return device_l1k2_gathered(devs, d_x, d_y, xrows, yrows_total, dim, d_idx, d_dist, transport);
+  });
+}
+
+long long spv_shard_lo(long long total, int shards, int r) {
+  if (shards < 1 || r < 0) return 0;
+  if (r >= shards) return total;
+  return shard_lo(total, shards, r);
 }
 
 int spv_cascade_device(const float *d_x, const float *d_y, int xrows, int yrows, int dim, int m,

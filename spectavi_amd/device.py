@@ -103,6 +103,50 @@ def l1k2(x, y, workspace=None):
     return idx, dist
 
 
+def shard_bounds(total, shards):
+    """[lo_0, lo_1, ..., total]: the contiguous balanced shards the library itself uses."""
+    clib.spv_shard_lo.restype = ct.c_longlong
+    clib.spv_shard_lo.argtypes = [ct.c_longlong, ct.c_int, ct.c_int]
+    return [int(clib.spv_shard_lo(int(total), int(shards), r)) for r in range(int(shards) + 1)]
+
+
+def l1k2_gathered(xs, ys, transport="rccl"):
+    """The sharded query loop inside ONE process (reference loop
+    src/BruteForceNnL1K2.h:92-93): xs[r] = replica of the database on GPU r, ys[r] = query shard r
+    (contiguous balanced shards, `shard_bounds`), one tensor per listed GPU.  Every GPU matches its
+    shard; the 16-byte (idx0, idx1, d0, d1) records are gathered on ys[0]'s GPU by ncclGather on the
+    library's ncclCommInitAll clique ("rccl") or by peer copies ("copy") and widened there.
+    Returns (idx int64 [N,2], dist int32 [N,2]) on that GPU.  Synchronous."""
+    if len(xs) != len(ys) or not xs:
+        raise ValueError("one database replica and one query shard per GPU")
+    G = len(xs)
+    for x, y in zip(xs, ys):
+        _need(x, torch.uint8, "x")
+        _need(y, torch.uint8, "y")
+        if x.device != y.device:
+            raise ValueError("replica and shard of one rank must share a GPU")
+    xrows, dim = xs[0].shape
+    if any(tuple(x.shape) != (xrows, dim) for x in xs) or any(y.shape[1] != dim for y in ys):
+        raise ValueError("database replicas must be identical in shape; all rows %d wide" % dim)
+    total = sum(int(y.shape[0]) for y in ys)
+    if [int(y.shape[0]) for y in ys] != [b - a for a, b in zip(shard_bounds(total, G)[:-1], shard_bounds(total, G)[1:])]:
+        raise ValueError("query shards must be the contiguous balanced split of the %d queries" % total)
+    root = ys[0].device
+    idx = torch.empty((total, 2), dtype=torch.int64, device=root)
+    dist = torch.empty((total, 2), dtype=torch.int32, device=root)
+    devs = (ct.c_int * G)(*[y.device.index for y in ys])
+    px = (ct.c_void_p * G)(*[x.data_ptr() for x in xs])
+    py = (ct.c_void_p * G)(*[y.data_ptr() for y in ys])
+    for y in ys:
+        torch.cuda.synchronize(y.device)  # the library runs on streams of its own
+    clib.spv_l1k2_gathered_device.restype = ct.c_int
+    clib.spv_l1k2_gathered_device.argtypes = [ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_void_p),
+                                              ct.POINTER(ct.c_void_p), ct.c_int, ct.c_longlong, ct.c_int, _vp, _vp, ct.c_int]
+    mode = {"rccl": 1, "copy": 2}[transport]
+    check(clib.spv_l1k2_gathered_device(G, devs, px, py, xrows, total, dim, idx.data_ptr(), dist.data_ptr(), mode))
+    return idx, dist
+
+
 def cascade(x, y, hash_dict, g=2, workspace=None, want_ncand=False):
     """Cascade-hash 2-NN on device: x,y float32 [rows,D]; hash_dict float32 [n,D,m]."""
     _need(x, torch.float32, "x")

@@ -137,6 +137,17 @@ def ransac_fit_sharded(x0, x1, samples, group=None, local_fn=None, device=None, 
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     local_fn = local_fn or _default_fit_fn
     npt = x0.shape[0]
+    samples = np.asarray(samples)
+    if samples.ndim != 2 or samples.shape[1] != 7 or samples.dtype != np.int32 or samples.shape[0] < 1:
+        raise ValueError("samples must be int32 [T,7] with T >= 1 (T < world size leaves some ranks without tries), got %s %s"
+                         % (samples.dtype, samples.shape))
+    # the same array on every rank, or best_try would index different subsets: a 2-word digest, compared
+    digest = torch.tensor([samples.shape[0], int(np.bitwise_xor.reduce(samples.astype(np.int64).reshape(-1) *
+                           (np.arange(samples.size, dtype=np.int64) % 8191 + 1)))], dtype=torch.int64, device=device)
+    digests = [torch.empty_like(digest) for _ in range(world)]
+    dist.all_gather(digests, digest, group=group)
+    if any(not torch.equal(dg, digest) for dg in digests):
+        raise ValueError("ransac_fit_sharded: `samples` differs between ranks")
     lo, hi = shard_bounds(len(samples), world, rank)
     r = local_fn(x0, x1, samples[lo:hi], **kw)
     found = r['best_try'] >= 0

@@ -15,7 +15,7 @@ def declared_symbols():
     for hdr in ("spectavi_amd.h", "NdArray.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        for m in re.finditer(r"^\s*(?:const\s+)?(?:void|int|size_t|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M):
+        for m in re.finditer(r"^\s*(?:const\s+)?(?:void|int|size_t|char|long long)\s*\*?\s*(\w+)\s*\(", text, flags=re.M):
             names.add(m.group(1))
     return sorted(names)
 

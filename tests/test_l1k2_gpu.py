@@ -239,6 +239,43 @@ def test_config5_full_shard(oracle):
     assert np.array_equal(dist[sub].cpu().numpy(), odist)
 
 
+def test_north_star_shape_1m_x_1m(oracle):
+    """north_star's target shape, the one bench.py's headline line is quoted on: 1,000,000 database
+    rows x 1,000,000 query rows, D = 128 (1e12 pairs, ~0.9 s), with the reference's test distribution
+    (uniform uint8, test/test_feature.py:112-115).  Size-independent properties over all rows --
+    planted exact copies in every database slice found at distance 0, the lower index first between
+    two exact copies, rows sorted / in range / distinct, reported distances equal to the true L1
+    distance on a strided sample (the reference's own test property, test/test_feature.py:116-121,
+    here per returned index) -- plus a 1024-query subsample compared bit for bit with the oracle
+    against the full database."""
+    import torch
+    from spectavi_amd import device
+    m = n = 1_000_000
+    g = torch.Generator(device="cuda").manual_seed(0xdeadbeef)
+    x = torch.randint(0, 256, (m, 128), dtype=torch.uint8, device="cuda", generator=g)
+    y = torch.randint(0, 256, (n, 128), dtype=torch.uint8, device="cuda", generator=g)
+    planted = torch.arange(0, 4096, device="cuda") * 244 + 3           # query rows
+    src = (torch.arange(0, 4096, device="cuda") * 244_141 + 5) % m      # database rows, all 16 slices
+    y[planted] = x[src]
+    x[999_999] = y[999_999]     # two exact copies of the last query: the last database row ...
+    x[41] = y[999_999]          # ... and an early one; the lower index must come first
+    idx, dist = device.l1k2(x, y)
+    torch.cuda.synchronize()
+    assert bool((dist[planted, 0] == 0).all()) and bool((idx[planted, 0] == src).all())
+    assert idx[999_999].tolist() == [41, 999_999] and dist[999_999].tolist() == [0, 0]
+    assert bool((dist[:, 0] <= dist[:, 1]).all())
+    assert bool((idx >= 0).all()) and bool((idx < m).all()) and bool((idx[:, 0] != idx[:, 1]).all())
+    sel = torch.arange(0, n, 61, device="cuda")
+    for c in range(2):
+        d = (x[idx[sel, c]].to(torch.int32) - y[sel].to(torch.int32)).abs().sum(1)
+        assert bool((d == dist[sel, c]).all())
+    sub = np.concatenate([np.arange(0, n, 978), [999_999]])
+    assert len(sub) >= 1024
+    oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y[sub].cpu().numpy(), nthreads=oracle.max_threads())
+    assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
+    assert np.array_equal(dist[sub].cpu().numpy(), odist)
+
+
 def test_large_host_output_uses_the_pinned_pipeline(oracle):
     """1.2M queries: the 19 MB index array comes back through the pinned, threaded download path
     (results of 16 MB and more); a strided sample against the oracle, every row against the

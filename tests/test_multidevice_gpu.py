@@ -1,10 +1,13 @@
 """GPU: in-process sharding of the host-array entry points over a device list.  The box has
 one GPU, so the list names device 0 three times (allowed): this exercises the shard bounds,
 the per-shard threads and the direct writes into output slices; results must not change."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture
@@ -290,6 +293,33 @@ def test_gathered_layout_three_ranks(oracle, three_ranks_copy_transport):
     assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T))
     device.profile_enable(False)
     assert device.profile_read("gather")[0] == 5 + 2 + 2    # five L1 calls, cascade records + ncand, two DLT calls
+
+
+def test_gathered_device_resident_form(oracle):
+    """spv_l1k2_gathered_device (what `bench.py --mode inlib` times): replicas and query shards
+    already in HBM, one rank per listed device, records gathered and widened on the first.  On a
+    one-GPU box: a real RCCL clique of one, and three ranks on device 0 over the peer-copy transport
+    with ragged shards -- both bit-equal to the oracle; bad shard splits are refused."""
+    import torch
+    import spectavi_amd
+    from spectavi_amd import device
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.integers(0, 256, (4099, 128), dtype=np.uint8)).cuda()
+    for nq, G, transport in ((1001, 1, "rccl"), (1001, 3, "copy"), (1002, 3, "copy"), (5, 4, "copy")):
+        y = rng.integers(0, 256, (nq, 128), dtype=np.uint8)
+        b = device.shard_bounds(nq, G)
+        assert b[0] == 0 and b[-1] == nq and all(0 <= b[i + 1] - b[i] - nq // G <= 1 for i in range(G))
+        ys = [torch.from_numpy(y[b[r]:b[r + 1]]).cuda() for r in range(G)]
+        idx, dist = device.l1k2_gathered([x] * G, ys, transport=transport)
+        oidx, odist = oracle.nn_bruteforcel1k2(x.cpu().numpy(), y, nthreads=8)
+        assert np.array_equal(idx.cpu().numpy().view(np.uint64), oidx) and np.array_equal(dist.cpu().numpy(), odist), (nq, G)
+    # sentinels through the records
+    idx, dist = device.l1k2_gathered([x[:1]] * 2, [torch.from_numpy(y[:3]).cuda(), torch.from_numpy(y[3:5]).cuda()], transport="copy")
+    assert bool((idx[:, 1] == -1).all()) and bool((dist[:, 1] == np.iinfo(np.int32).max).all())
+    with pytest.raises(ValueError, match="balanced"):
+        device.l1k2_gathered([x, x], [torch.from_numpy(y[:1]).cuda(), torch.from_numpy(y[1:5]).cuda()], transport="copy")
+    with pytest.raises(spectavi_amd.SpectaviError, match="listed twice"):
+        device.l1k2_gathered([x, x], [torch.from_numpy(y[:3]).cuda(), torch.from_numpy(y[3:5]).cuda()], transport="rccl")
 
 
 def _hip_rank(rank, world, port, nq, out_path):
