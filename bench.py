@@ -417,11 +417,17 @@ def run_rank(args):
 
 
 def _store_barrier(dist, rank, world):
-    """Host-side barrier over the rendezvous store (no GPU work while rank 0 times the CPU leg)."""
+    """Host-side barrier over the rendezvous store (no GPU work while rank 0 times the CPU leg).
+    Rank 0 hosts the store, so it leaves last: the others acknowledge with their final store call."""
     store = dist.distributed_c10d._get_default_store()
     store.add("spectavi_bench_done", 1)
     while int(store.add("spectavi_bench_done", 0)) < world:
         time.sleep(0.2)
+    if rank != 0:
+        store.add("spectavi_bench_ack", 1)
+    else:
+        while int(store.add("spectavi_bench_ack", 0)) < world - 1:
+            time.sleep(0.05)
 
 
 # ---------------------------------------------------------------------------------------------

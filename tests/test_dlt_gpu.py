@@ -141,12 +141,12 @@ def test_device_path_10m_noisy_config4(oracle):
     assert float(((X * X).sum(1) - 1).abs().max()) < 1e-12
     assert bool((X[:, 3] >= 0).all())
     # inliers: the error is a sum of two 2-D residual norms of N(0, 1e-3) noise (a few 1e-3), and the
-    # triangulated point is the planted one up to noise x depth^2 / baseline
+    # triangulated point is the planted one up to ~ noise x depth^2 / baseline (1e-3 x 25 / 1)
     e_in = err[inl]
     assert float(e_in.median()) < 5e-3 and float((e_in < 2e-2).double().mean()) > 0.999
     behind = (Xw[:, 2] > 1.0) & inl                                   # well in front of camera 0
     dX = (X[behind] / X[behind, 3:4] - Xw[behind]).abs().max(1).values
-    assert float(dX.median()) < 2e-2
+    assert float(dX.median()) < 5e-2
     # outliers are inconsistent correspondences: their error is large, which is what RANSAC keys on
     assert float((err[outl] > 2e-2).double().mean()) > 0.9
 
