@@ -3,15 +3,17 @@
 // TEST INFRASTRUCTURE ONLY (see oracle_l1k2.cpp header): never imported, linked
 // or called from spectavi_amd/.
 //
-// THIS IS NOT THE ORACLE for the DLT rows: it executes, with std::fma, exactly the sequence of
-// IEEE operations spectavi_amd/csrc/dlt.hip executes (square-root-free Gram-Schmidt + inverse
-// iteration with a one-sided Hestenes Jacobi fallback; Jacobi alone for RANSAC scoring; sign
-// canonicalised to X[3] >= 0), so that "device == host, bit for bit" can be asserted: that pins
-// determinism of the device code (no miscompiled FMA contraction, no lane-dependent path, inf/nan
-// in the same places), NOT that X is the right singular vector of the smallest singular value.
-// Correctness of the HIP path is judged against oracle_jacobisvd.cpp (the restatement of the
-// reference's Eigen::JacobiSVD arithmetic, src/DltTriangulator.h:36-86) and against LAPACK in
-// tests/test_dlt_gpu.py, tests/fuzz_gpu.py and tests/test_oracle.py.
+// THIS IS NOT THE ORACLE for the DLT rows: it executes, with std::fma, the sequence of operations
+// spectavi_amd/csrc/dlt.hip executes (square-root-free Gram-Schmidt + division-free inverse
+// iteration with a one-sided Hestenes Jacobi fallback; sign canonicalised to X[3] >= 0), with the
+// exact 1/x and 1/sqrt(x) where the kernel uses v_rcp_f64 / v_rsq_f64 + two Newton steps (< 1 ulp
+// apart).  "device == host to a few ulps times the point's conditioning, inf/nan in the same
+// places" pins determinism of the device code (no miscompiled FMA contraction, no lane- or
+// shape-dependent path), NOT that X is the right singular vector of the smallest singular value.
+// (Until round 3 the kernel used IEEE divisions and the agreement was bit for bit; they were a
+// third of its issue time.)  Correctness of the HIP path is judged against oracle_jacobisvd.cpp
+// (the restatement of the reference's Eigen::JacobiSVD arithmetic, src/DltTriangulator.h:36-86)
+// and against LAPACK in tests/test_dlt_gpu.py, tests/fuzz_gpu.py and tests/test_oracle.py.
 
 #include <cmath>
 #include <cstdint>
@@ -85,14 +87,15 @@ inline void null_jacobi(const double (&A0)[4][4], double (&xv)[4]) {
 // ---- null vector, method 2: square-root-free Gram-Schmidt + inverse iteration ------------
 // A = Q U with orthogonal (not normalised) columns q_j, d_j = |q_j|^2, U unit upper triangular
 // (modified Gram-Schmidt, no pivoting), so A^T A = U^T D U; the smallest right singular vector
-// of A by inverse iteration on U^T D U (two unit-triangular solves and a diagonal scaling per
-// step, contraction (sigma4/sigma3)^2, iterate kept at max-norm 1 from step 2 on).  4 to 8 steps; returns
-// false when the last step still moved the vector by more than 1e-12 (ill-separated sigma3,
-// sigma4, or inf/nan from a degenerate A) -- the caller then falls back to method 1.
+// of A by inverse iteration on U^T D U, the diagonal solve scaled by d_3 (y_j = z_j d_3 / d_j,
+// y_3 = z_3), iterates left un-normalised, convergence = direction of consecutive iterates equal
+// to 1e-12 (same schedule as the HIP kernel: steps 0, 1, 2, then tested steps 3..7).  Returns false
+// when the last step still moved the direction or the iterate left the range -- the caller then
+// falls back to method 1.
 inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
   double col[4][4];  // col[c][r]
   double U[4][4] = {{0}};
-  double id[4];
+  double g[3] = {0, 0, 0};
   for (int c = 0; c < 4; ++c)
     for (int r = 0; r < 4; ++r) col[c][r] = A0[r][c];
   double tiny2 = 0.0;
@@ -101,49 +104,58 @@ inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4])
     for (int r = 0; r < 4; ++r) d = std::fma(col[j][r], col[j][r], d);
     if (j == 0) tiny2 = 4.930380657631324e-32 * d;  // eps^2 |a_0|^2
     if (!(d > tiny2)) d = tiny2;
-    id[j] = 1.0 / d;
+    if (j == 3) {
+      for (int k = 0; k < 3; ++k) g[k] *= d;
+      break;
+    }
+    const double idj = 1.0 / d;
+    g[j] = idj;
     for (int k = j + 1; k < 4; ++k) {
       double s = 0.0;
       for (int r = 0; r < 4; ++r) s = std::fma(col[j][r], col[k][r], s);
-      const double u = s * id[j];
+      const double u = s * idj;
       U[j][k] = u;
       for (int r = 0; r < 4; ++r) col[k][r] = std::fma(-u, col[j][r], col[k][r]);
     }
   }
-  // step 0 from e4 is a bare back-substitution, step 1 runs without normalisation; from step 2
-  // on the iterate is brought to max-norm 1 and tested (same schedule as the HIP kernel)
   double v[4];
   v[3] = 1.0;
   v[2] = -U[2][3];
   v[1] = std::fma(-U[1][2], v[2], -U[1][3]);
   v[0] = std::fma(-U[0][1], v[1], std::fma(-U[0][2], v[2], -U[0][3]));
   double w[4];
-  auto step = [&]() {  // w = (U^T D U)^-1 v
+  auto step = [&]() {  // w = d_3 (U^T D U)^-1 v
     const double z0 = v[0];
     const double z1 = std::fma(-U[0][1], z0, v[1]);
     const double z2 = std::fma(-U[1][2], z1, std::fma(-U[0][2], z0, v[2]));
     const double z3 = std::fma(-U[2][3], z2, std::fma(-U[1][3], z1, std::fma(-U[0][3], z0, v[3])));
-    const double y0 = z0 * id[0], y1 = z1 * id[1], y2 = z2 * id[2], y3 = z3 * id[3];
-    w[3] = y3;
+    const double y0 = z0 * g[0], y1 = z1 * g[1], y2 = z2 * g[2];
+    w[3] = z3;
     w[2] = std::fma(-U[2][3], w[3], y2);
     w[1] = std::fma(-U[1][3], w[3], std::fma(-U[1][2], w[2], y1));
     w[0] = std::fma(-U[0][3], w[3], std::fma(-U[0][2], w[2], std::fma(-U[0][1], w[1], y0)));
   };
-  step();
-  for (int c = 0; c < 4; ++c) v[c] = w[c];
-  double delta = 1.0;
-  for (int it = 2; it < 8; ++it) {
+  auto maxabs = [](const double (&a)[4]) {
+    return std::fmax(std::fmax(std::fabs(a[0]), std::fabs(a[1])), std::fmax(std::fabs(a[2]), std::fabs(a[3])));
+  };
+  for (int it = 1; it <= 2; ++it) {
     step();
-    const double big = std::fmax(std::fmax(std::fabs(w[0]), std::fabs(w[1])), std::fmax(std::fabs(w[2]), std::fabs(w[3])));
-    const double inv = 1.0 / big;
-    double n[4];
-    for (int c = 0; c < 4; ++c) n[c] = w[c] * inv;
-    delta = std::fmax(std::fmax(std::fabs(n[0] - v[0]), std::fabs(n[1] - v[1])),
-                      std::fmax(std::fabs(n[2] - v[2]), std::fabs(n[3] - v[3])));
-    for (int c = 0; c < 4; ++c) v[c] = n[c];
-    if (delta <= 1e-12) break;
+    for (int c = 0; c < 4; ++c) v[c] = w[c];
   }
-  if (!(delta <= 1e-12)) return false;
+  double bv = maxabs(v);
+  bool ok = false;
+  for (int it = 3; it < 8; ++it) {
+    step();
+    const double bw = maxabs(w);
+    double e[4];
+    for (int c = 0; c < 4; ++c) e[c] = std::fabs(std::fma(w[c], bv, -(v[c] * bw)));
+    const double bound = 1e-12 * (bw * bv);
+    ok = (maxabs(e) <= bound) && (bound >= 1e-290) && (bound <= 1e290);
+    for (int c = 0; c < 4; ++c) v[c] = w[c];
+    bv = bw;
+    if (ok) break;
+  }
+  if (!ok) return false;
   for (int c = 0; c < 4; ++c) xv[c] = v[c];
   return true;
 }
@@ -153,8 +165,9 @@ inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4])
 // (hypothesis, point) pair is this function's); fast = false: method 1 only.
 inline void dlt_solve(const double *P0, const double *P1, const double *x, const double *xp,
                       Solve &out, bool fast = true) {
-  const double u = x[0] / x[2], v = x[1] / x[2];
-  const double up = xp[0] / xp[2], vp = xp[1] / xp[2];
+  const double ix = 1.0 / x[2], iy = 1.0 / xp[2];  // one reciprocal per view, as the kernel
+  const double u = x[0] * ix, v = x[1] * ix;
+  const double up = xp[0] * iy, vp = xp[1] * iy;
   double A[4][4];
   for (int c = 0; c < 4; ++c) {
     A[0][c] = std::fma(u, P0[8 + c], -P0[0 + c]);
@@ -164,9 +177,14 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
   }
   double xv[4];
   if (!(fast && null_gs_inverse_iteration(A, xv))) null_jacobi(A, xv);
-  double nrm = 0.0;
-  for (int i = 0; i < 4; ++i) nrm = std::fma(xv[i], xv[i], nrm);
-  nrm = std::sqrt(nrm);
+  // max-norm into [0.5, 1) by an exact power of two, then the unit 2-norm and the canonical sign
+  const double big = std::fmax(std::fmax(std::fabs(xv[0]), std::fabs(xv[1])), std::fmax(std::fabs(xv[2]), std::fabs(xv[3])));
+  int ex = 0;
+  if (std::isfinite(big) && big != 0.0) std::frexp(big, &ex);
+  double sv[4];
+  for (int i = 0; i < 4; ++i) sv[i] = std::ldexp(xv[i], -ex);
+  double nrm2 = 0.0;
+  for (int i = 0; i < 4; ++i) nrm2 = std::fma(sv[i], sv[i], nrm2);
   bool neg;
   if (xv[3] != 0.0)
     neg = xv[3] < 0.0;
@@ -176,8 +194,9 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
     neg = xv[1] < 0.0;
   else
     neg = xv[2] < 0.0;
-  const double scale = 1.0 / (neg ? -nrm : nrm);
-  for (int i = 0; i < 4; ++i) out.X[i] = xv[i] * scale;
+  const double q = 1.0 / std::sqrt(nrm2);
+  const double scale = neg ? -q : q;
+  for (int i = 0; i < 4; ++i) out.X[i] = sv[i] * scale;
   out.u = u;
   out.v = v;
   out.up = up;
@@ -190,6 +209,17 @@ inline void reproject(const double *P, const double *X, double *r) {
     for (int c = 0; c < 4; ++c) a = std::fma(P[4 * k + c], X[c], a);
     r[k] = a;
   }
+}
+
+// sum of the two image-plane residual norms (reference src/DltTriangulator.h:67-74), one reciprocal
+// per camera as the kernel; r0 / r1 = P X
+inline double reprojection_error(const double *P0, const double *P1, const Solve &s, double *r0, double *r1) {
+  reproject(P0, s.X, r0);
+  reproject(P1, s.X, r1);
+  const double i0 = 1.0 / r0[2], i1 = 1.0 / r1[2];
+  const double e0x = std::fma(r0[0], i0, -s.u), e0y = std::fma(r0[1], i0, -s.v);
+  const double e1x = std::fma(r1[0], i1, -s.up), e1y = std::fma(r1[1], i1, -s.vp);
+  return std::sqrt(std::fma(e0x, e0x, e0y * e0y)) + std::sqrt(std::fma(e1x, e1x, e1y * e1y));
 }
 
 inline double det3(const double *P) {
@@ -219,11 +249,7 @@ void oracle_dlt_mirror_reprojection_error(const double *P0, const double *P1, in
     Solve s;
     dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
     double r0[3], r1[3];
-    reproject(P0, s.X, r0);
-    reproject(P1, s.X, r1);
-    const double e0x = r0[0] / r0[2] - s.u, e0y = r0[1] / r0[2] - s.v;
-    const double e1x = r1[0] / r1[2] - s.up, e1y = r1[1] / r1[2] - s.vp;
-    dst[i] = std::sqrt(std::fma(e0x, e0x, e0y * e0y)) + std::sqrt(std::fma(e1x, e1x, e1y * e1y));
+    dst[i] = reprojection_error(P0, P1, s, r0, r1);
   }
 }
 
@@ -262,11 +288,7 @@ void oracle_dlt_mirror_score_hypotheses(const double *P0, const double *P1s, int
       Solve s;
       dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s, /*fast=*/true);
       double r0[3], r1[3];
-      reproject(P0, s.X, r0);
-      reproject(P1, s.X, r1);
-      const double e0x = r0[0] / r0[2] - s.u, e0y = r0[1] / r0[2] - s.v;
-      const double e1x = r1[0] / r1[2] - s.up, e1y = r1[1] / r1[2] - s.vp;
-      const double err = std::sqrt(std::fma(e0x, e0x, e0y * e0y)) + std::sqrt(std::fma(e1x, e1x, e1y * e1y));
+      const double err = reprojection_error(P0, P1, s, r0, r1);
       const double dc0 = s0 / n0 * r0[2] / s.X[3];
       const double dc1 = s1 / n1 * r1[2] / s.X[3];
       const bool in = (err <= max_error) && (dc0 > 0) && (dc1 > 0);

@@ -14,8 +14,11 @@
 //   the column of smallest norm is the answer).
 //
 // Every fused multiply-add is written explicitly and implicit contraction is off
-// (-ffp-contract=off), so the CPU oracle, which executes the same operation
-// sequence with std::fma, reproduces the result bit for bit.
+// (-ffp-contract=off).  Reciprocals and reciprocal square roots are v_rcp_f64 / v_rsq_f64 plus
+// two Newton steps (< 1 ulp) instead of the IEEE division / square-root sequences (round 3: they
+// were a third of the solve's issue time), so the host mirror of this operation sequence
+// (oracle/oracle_dlt_mirror.cpp, exact 1/x and 1/sqrt(x) in their place) agrees to a few ulps
+// times the conditioning of the point, not bit for bit.
 //
 // Sign: Eigen's sign of V.col(3) is arbitrary; the result is canonicalised to
 // X[3] >= 0 (first nonzero component positive when X[3] == 0).
@@ -32,6 +35,43 @@ struct Cameras {
   double p0[12];
   double p1[12];
 };
+
+// ---- fp64 reciprocals without the IEEE sequences ------------------------------------------
+// Measured on gfx950 (tools/exp/f64_rate.hip, profiles/r03_f64_rate.txt): v_fma / v_mul / v_add /
+// v_div_scale / v_div_fmas / v_div_fixup / v_ldexp _f64 issue every 4 cycles per SIMD, v_rcp_f64 /
+// v_rsq_f64 / v_sqrt_f64 every 16 and are good to 2^-24 (4.6e-8); one Newton step brings them to
+// 2e-15, two to 1.1e-16 / 1.4e-16 (worst of 1M values, against 2^-53 = 1.1e-16).  An IEEE x / y
+// compiles to 2 v_div_scale + v_rcp + 7 fma / mul + v_div_fmas + v_div_fixup = ~60 issue cycles, an
+// IEEE sqrt to ~80; rcp_nr2 is 32, rsqrt_nr2 44.
+__device__ __forceinline__ double rcp_nr2(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+// the same, keeping IEEE's answers at the ends: 1/0 = inf, 1/inf = 0 (Newton turns both into nan)
+__device__ __forceinline__ double rcp_nr2_ieee(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r0, 1.0);
+  double r = __builtin_fma(r0, e, r0);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return (r0 == 0.0 || __builtin_isinf(r0)) ? r0 : r;
+}
+__device__ __forceinline__ double rsqrt_nr2(double x) {
+  double q = __builtin_amdgcn_rsq(x);
+  double t = __builtin_fma(-(x * q), q, 1.0);
+  q = __builtin_fma(0.5 * q, t, q);
+  t = __builtin_fma(-(x * q), q, 1.0);
+  return __builtin_fma(0.5 * q, t, q);
+}
+// sqrt(s) for s >= 0 as s * rsqrt(s); zero and the range whose reciprocal root would overflow or
+// lose bits take the IEEE instruction sequence (exact zeros occur: noise-free points reproject exactly)
+__device__ __forceinline__ double sqrt_fast(double s) {
+  if (!(s >= 0x1p-900)) return sqrt(s);
+  return s * rsqrt_nr2(s);
+}
 
 // ---- null vector, method 1: one-sided (Hestenes) Jacobi, always converges ----------------
 __device__ __forceinline__ void null_jacobi(const double (&A0)[4][4], double (&xv)[4]) {
@@ -69,7 +109,7 @@ __device__ __forceinline__ void null_jacobi(const double (&A0)[4][4], double (&x
           const double g2 = 2.0 * gamma;
           const double hh = sqrt(__builtin_fma(dd, dd, g2 * g2));
           const double tn = g2 / (dd + (dd < 0.0 ? -hh : hh));
-          const double cs = 1.0 / sqrt(__builtin_fma(tn, tn, 1.0));
+          const double cs = rsqrt_nr2(__builtin_fma(tn, tn, 1.0));  // argument >= 1
           const double sn = cs * tn;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -108,15 +148,23 @@ __device__ __forceinline__ void null_jacobi(const double (&A0)[4][4], double (&x
 // triangular (modified Gram-Schmidt, no pivoting: only U and d are used, and those are
 // backward stable whatever the column order), so A^T A = U^T D U.  The smallest right singular
 // vector of A is found by inverse iteration on U^T D U: two unit-triangular solves and one
-// diagonal scaling per step, contraction (sigma4/sigma3)^2; the iterate is kept at max-norm 1
-// (one division, no square root).  About 450 fp64 instructions for 4 steps against about 3000
-// for method 1.  Returns false when the last of up to 8 steps still moved the vector by more
-// than 1e-12 (ill-separated sigma3, sigma4, or a degenerate A that produced inf/nan); the
-// caller then falls back to method 1.  Operation order mirrors the oracle exactly.
+// diagonal scaling per step, contraction (sigma4/sigma3)^2.  Division-free after the three
+// reciprocals 1/d_0..1/d_2 the orthogonalisation needs: the diagonal solve is scaled by d_3
+// (y_j = z_j d_3 / d_j, y_3 = z_3), which also keeps the un-normalised iterates from growing by
+// 1/sigma4^2 per step (d_3 >= sigma4^2 is the squared distance of the last column from the span of
+// the others: the growth per step is d_3 / sigma4^2, O(1) for a consistent point), and the
+// convergence test compares DIRECTIONS of consecutive un-normalised iterates,
+//   max_i |w_i max|v| - v_i max|w|| <= 1e-12 max|v| max|w|
+// (no sign ambiguity: (A^T A)^-1 is positive definite).  Steps 0 (a bare back-substitution from
+// e4), 1 and 2 run unconditionally, then a point stops at the first step that moved its direction
+// by no more than 1e-12 (step 3 for pixel noise 1e-3; at most 8).  ~300 fp64 instructions.
+// Returns false when the last step still moved it (ill-separated sigma3, sigma4), or the
+// iterate left the range (inf / nan from a degenerate A, overflow of a badly conditioned one);
+// the caller then falls back to method 1.
 __device__ __forceinline__ bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
   double col[4][4];  // col[c][r]
   double U[4][4];    // strictly upper part used
-  double id[4];      // 1 / d_j
+  double g[3];       // d_3 / d_j
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -129,60 +177,69 @@ __device__ __forceinline__ bool null_gs_inverse_iteration(const double (&A0)[4][
     for (int r = 0; r < 4; ++r) d = __builtin_fma(col[j][r], col[j][r], d);
     if (j == 0) tiny2 = 4.930380657631324e-32 * d;  // eps^2 |a_0|^2
     if (!(d > tiny2)) d = tiny2;
-    id[j] = 1.0 / d;
+    if (j == 3) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[k] *= d;
+      break;
+    }
+    const double idj = rcp_nr2(d);
+    g[j] = idj;
 #pragma unroll
     for (int k = j + 1; k < 4; ++k) {
       double s = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) s = __builtin_fma(col[j][r], col[k][r], s);
-      const double u = s * id[j];
+      const double u = s * idj;
       U[j][k] = u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) col[k][r] = __builtin_fma(-u, col[j][r], col[k][r]);
     }
   }
-  // step 0 from e4 is a bare back-substitution (U^T e4 = e4, the diagonal scaling only changes
-  // the length), step 1 runs without normalisation; from step 2 on the iterate is brought to
-  // max-norm 1 and a point stops at the first step that moved it by no more than 1e-12
-  // (step 3 for pixel noise around 1e-3; at most 8 steps)
   double v3 = 1.0;
   double v2 = -U[2][3];
   double v1 = __builtin_fma(-U[1][2], v2, -U[1][3]);
   double v0 = __builtin_fma(-U[0][1], v1, __builtin_fma(-U[0][2], v2, -U[0][3]));
   double w0, w1, w2, w3;
-  auto step = [&]() {  // w = (U^T D U)^-1 v
+  auto step = [&]() {  // w = d_3 (U^T D U)^-1 v
     // U^T z = v
     const double z0 = v0;
     const double z1 = __builtin_fma(-U[0][1], z0, v1);
     const double z2 = __builtin_fma(-U[1][2], z1, __builtin_fma(-U[0][2], z0, v2));
     const double z3 = __builtin_fma(-U[2][3], z2, __builtin_fma(-U[1][3], z1, __builtin_fma(-U[0][3], z0, v3)));
-    // D y = z
-    const double y0 = z0 * id[0], y1 = z1 * id[1], y2 = z2 * id[2], y3 = z3 * id[3];
+    // D y = d_3 z
+    const double y0 = z0 * g[0], y1 = z1 * g[1], y2 = z2 * g[2];
     // U w = y
-    w3 = y3;
+    w3 = z3;
     w2 = __builtin_fma(-U[2][3], w3, y2);
     w1 = __builtin_fma(-U[1][3], w3, __builtin_fma(-U[1][2], w2, y1));
     w0 = __builtin_fma(-U[0][3], w3, __builtin_fma(-U[0][2], w2, __builtin_fma(-U[0][1], w1, y0)));
   };
-  step();
-  v0 = w0;
-  v1 = w1;
-  v2 = w2;
-  v3 = w3;
-  double delta = 1.0;
-  for (int it = 2; it < 8; ++it) {
+#pragma unroll
+  for (int it = 1; it <= 2; ++it) {
     step();
-    const double big = fmax(fmax(fabs(w0), fabs(w1)), fmax(fabs(w2), fabs(w3)));
-    const double inv = 1.0 / big;
-    const double n0 = w0 * inv, n1 = w1 * inv, n2 = w2 * inv, n3 = w3 * inv;
-    delta = fmax(fmax(fabs(n0 - v0), fabs(n1 - v1)), fmax(fabs(n2 - v2), fabs(n3 - v3)));
-    v0 = n0;
-    v1 = n1;
-    v2 = n2;
-    v3 = n3;
-    if (delta <= 1e-12) break;
+    v0 = w0;
+    v1 = w1;
+    v2 = w2;
+    v3 = w3;
   }
-  if (!(delta <= 1e-12)) return false;
+  double bv = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+  bool ok = false;
+  for (int it = 3; it < 8; ++it) {
+    step();
+    const double bw = fmax(fmax(fabs(w0), fabs(w1)), fmax(fabs(w2), fabs(w3)));
+    const double e0 = fabs(__builtin_fma(w0, bv, -(v0 * bw))), e1 = fabs(__builtin_fma(w1, bv, -(v1 * bw)));
+    const double e2 = fabs(__builtin_fma(w2, bv, -(v2 * bw))), e3 = fabs(__builtin_fma(w3, bv, -(v3 * bw)));
+    const double bound = 1e-12 * (bw * bv);
+    // a bound of 0 or inf is an iterate out of range, never agreement
+    ok = (fmax(fmax(e0, e1), fmax(e2, e3)) <= bound) && (bound >= 1e-290) && (bound <= 1e290);
+    v0 = w0;
+    v1 = w1;
+    v2 = w2;
+    v3 = w3;
+    bv = bw;
+    if (ok) break;
+  }
+  if (!ok) return false;
   xv[0] = v0;
   xv[1] = v1;
   xv[2] = v2;
@@ -197,10 +254,11 @@ __device__ __forceinline__ bool null_gs_inverse_iteration(const double (&A0)[4][
 __device__ __forceinline__ void dlt_matrix(const Cameras &cam, double x0, double x1, double x2, double y0,
                                            double y1, double y2, double (&A)[4][4], double &u, double &v,
                                            double &up, double &vp) {
-  u = x0 / x2;
-  v = x1 / x2;
-  up = y0 / y2;
-  vp = y1 / y2;
+  const double ix = rcp_nr2_ieee(x2), iy = rcp_nr2_ieee(y2);  // one reciprocal per view; x / 0 stays +-inf or nan
+  u = x0 * ix;
+  v = x1 * ix;
+  up = y0 * iy;
+  vp = y1 * iy;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     A[0][c] = __builtin_fma(u, cam.p0[8 + c], -cam.p0[0 + c]);
@@ -210,12 +268,18 @@ __device__ __forceinline__ void dlt_matrix(const Cameras &cam, double x0, double
   }
 }
 
-// unit 2-norm (V is orthogonal up to rounding) and the canonical sign
+// unit 2-norm and the canonical sign.  xv is an un-normalised iterate of any magnitude (or a
+// column of the Jacobi's V): it is first brought to max-norm in [0.5, 1) by an exact power of two,
+// so the sum of squares neither overflows nor underflows.
 __device__ __forceinline__ void dlt_finish(const double (&xv)[4], double (&X)[4]) {
-  double nrm = 0.0;
+  const double big = fmax(fmax(fabs(xv[0]), fabs(xv[1])), fmax(fabs(xv[2]), fabs(xv[3])));
+  const int ex = -__builtin_amdgcn_frexp_exp(big);  // 0 for big = 0 / inf / nan
+  double sv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) nrm = __builtin_fma(xv[i], xv[i], nrm);
-  nrm = sqrt(nrm);
+  for (int i = 0; i < 4; ++i) sv[i] = __builtin_amdgcn_ldexp(xv[i], ex);
+  double nrm2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nrm2 = __builtin_fma(sv[i], sv[i], nrm2);
   bool neg = false;
   if (xv[3] != 0.0)
     neg = xv[3] < 0.0;
@@ -225,9 +289,34 @@ __device__ __forceinline__ void dlt_finish(const double (&xv)[4], double (&X)[4]
     neg = xv[1] < 0.0;
   else
     neg = xv[2] < 0.0;
-  const double scale = 1.0 / (neg ? -nrm : nrm);
+  const double q = rsqrt_nr2(nrm2);
+  const double scale = neg ? -q : q;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) X[i] = xv[i] * scale;
+  for (int i = 0; i < 4; ++i) X[i] = sv[i] * scale;
+}
+
+// reprojection_error() of reference src/DltTriangulator.h:61-62, 67-74 for a solved point: the sum
+// of the two image-plane residual norms.  One reciprocal per camera; z0 / z1 = the depths P X [2].
+__device__ __forceinline__ double reprojection_error(const Cameras &cam, const double (&X)[4], double u, double v,
+                                                     double up, double vp, double &z0, double &z1) {
+  double r0[3], r1[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
+      b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
+    }
+    r0[r] = a;
+    r1[r] = b;
+  }
+  z0 = r0[2];
+  z1 = r1[2];
+  const double i0 = rcp_nr2_ieee(r0[2]), i1 = rcp_nr2_ieee(r1[2]);
+  const double e0x = __builtin_fma(r0[0], i0, -u), e0y = __builtin_fma(r0[1], i0, -v);
+  const double e1x = __builtin_fma(r1[0], i1, -up), e1y = __builtin_fma(r1[1], i1, -vp);
+  return sqrt_fast(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt_fast(__builtin_fma(e1x, e1x, e1y * e1y));
 }
 
 // FAST: method 2 with method 1 as fallback (consistent correspondences converge in 3-4 steps;
@@ -284,22 +373,8 @@ __global__ __launch_bounds__(kDltThreads) void dlt_kernel(Cameras cam, long long
       double4 *o = reinterpret_cast<double4 *>(dst) + p;
       *o = make_double4(X[0], X[1], X[2], X[3]);
     } else {
-      // reference src/DltTriangulator.h:61-62, 67-74
-      double r0[3], r1[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
-          b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
-        }
-        r0[r] = a;
-        r1[r] = b;
-      }
-      const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
-      const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
-      dst[p] = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
+      double z0, z1;
+      dst[p] = reprojection_error(cam, X, u, v, up, vp, z0, z1);
     }
   }
 }
@@ -321,26 +396,13 @@ __device__ __forceinline__ double det3_left(const double *P) {
 // reprojection_error() <= max_error && is_infront_both_cameras() (src/DltTriangulator.h:67-86)
 __device__ __forceinline__ bool score_inlier(const Cameras &cam, const double (&X)[4], double u, double v,
                                              double up, double vp, double max_error) {
-  double r0[3], r1[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a = __builtin_fma(cam.p0[4 * r + c], X[c], a);
-      b = __builtin_fma(cam.p1[4 * r + c], X[c], b);
-    }
-    r0[r] = a;
-    r1[r] = b;
-  }
-  const double e0x = r0[0] / r0[2] - u, e0y = r0[1] / r0[2] - v;
-  const double e1x = r1[0] / r1[2] - up, e1y = r1[1] / r1[2] - vp;
-  const double err = sqrt(__builtin_fma(e0x, e0x, e0y * e0y)) + sqrt(__builtin_fma(e1x, e1x, e1y * e1y));
+  double z0, z1;
+  const double err = reprojection_error(cam, X, u, v, up, vp, z0, z1);
   const double s0 = det3_left(cam.p0) < 0 ? -1.0 : 1.0, s1 = det3_left(cam.p1) < 0 ? -1.0 : 1.0;
   const double n0 = cam.p0[2] * cam.p0[2] + cam.p0[6] * cam.p0[6] + cam.p0[10] * cam.p0[10];
   const double n1 = cam.p1[2] * cam.p1[2] + cam.p1[6] * cam.p1[6] + cam.p1[10] * cam.p1[10];
-  const double dc0 = s0 / n0 * r0[2] / X[3];
-  const double dc1 = s1 / n1 * r1[2] / X[3];
+  const double dc0 = s0 / n0 * z0 / X[3];
+  const double dc1 = s1 / n1 * z1 / X[3];
   return (err <= max_error) && (dc0 > 0) && (dc1 > 0);
 }
 

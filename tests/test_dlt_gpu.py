@@ -5,8 +5,10 @@
   * the reference's DEFINITION with LAPACK as the solver (tests/dlt_checks.py): ||A X|| <= sigma4,
     |<X, v4>| >= 1 - 1e-9 where the singular-value gap allows, reprojection error within 1e-6
     relative (north_star's float tolerance);
-  * the host MIRROR of the kernel's own operation sequence (oracle/oracle_dlt_mirror.cpp), bit for
-    bit: determinism of the device code, not correctness.
+  * the host MIRROR of the kernel's own operation sequence (oracle/oracle_dlt_mirror.cpp), to a
+    few ulps times the point's conditioning (dlt_checks.check_against_mirror; bit for bit until
+    round 3 replaced the kernel's IEEE divisions by v_rcp_f64 + Newton steps): determinism of the
+    device code, not correctness.
 """
 import numpy as np
 import pytest
@@ -15,9 +17,9 @@ from tests import dlt_checks as dc
 
 pytestmark = pytest.mark.gpu
 
-# fp64 tolerance vs the mirror.  The HIP kernel and the mirror execute the same IEEE operation
-# sequence with contraction disabled, so they are expected to agree exactly; the
-# bound below only allows for a non-correctly-rounded device sqrt/div.
+# fp64 tolerance vs the mirror on well-conditioned batches.  The HIP kernel and the mirror execute the
+# same operation sequence with contraction disabled, except that the kernel's reciprocals and
+# reciprocal square roots are v_rcp_f64 / v_rsq_f64 + two Newton steps (< 1 ulp from exact).
 RTOL = 1e-12
 
 
@@ -199,8 +201,8 @@ def _essential_cameras(rng):
 
 
 def test_score_hypotheses_matches_oracle(oracle):
-    """RANSAC scoring (reference src/RansacFitter.h:59-95): counts and masks bit-equal to the
-    oracle; the true camera wins."""
+    """RANSAC scoring (reference src/RansacFitter.h:59-95): counts and masks equal to the oracle's
+    wherever the error is not on the threshold; the true camera wins."""
     from spectavi_amd import mvg
     rng = np.random.default_rng(12)
     P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
@@ -214,13 +216,15 @@ def test_score_hypotheses_matches_oracle(oracle):
     xp[::7] = rng.standard_normal((len(xp[::7]), 3))          # outliers
     P1s = np.stack(cams + [rng.standard_normal((3, 4)) for _ in range(3)])
     counts, mask = mvg.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2, return_mask=True)
-    mcounts, mmask = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, 1e-2)
-    assert np.array_equal(mask, mmask)
-    assert np.array_equal(counts, mcounts) and np.array_equal(counts, mask.sum(1))
+    assert np.array_equal(counts, mask.sum(1))
     # the oracle (a JacobiSVD solve per point and hypothesis, src/RansacFitter.h:59-73): identical
-    # decisions except where its own error is within 1e-9 relative of the threshold
+    # decisions except where its own error is within 1e-9 relative of the threshold; the same for the
+    # host mirror of the kernel's operation sequence (a few ulps from the kernel)
     ocounts, omask, oerr = oracle.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2, return_err=True)
     clear_o = np.abs(oerr - 1e-2) > 1e-11
+    mcounts, mmask = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, 1e-2)
+    assert np.array_equal(np.asarray(mask, bool)[clear_o], np.asarray(mmask, bool)[clear_o])
+    assert np.all(np.abs(counts - mcounts) <= (~clear_o).sum(1))
     assert np.array_equal(np.asarray(mask, bool)[clear_o], omask[clear_o])
     assert np.all(np.abs(counts - ocounts) <= (~clear_o).sum(1))
     assert counts.argmax() == 0 and counts[0] > 0.8 * npt * 6 / 7
@@ -236,9 +240,9 @@ def test_score_hypotheses_matches_oracle(oracle):
 
 def test_many_camera_pairs(oracle):
     """30 random camera pairs (every fifth with almost no baseline, every seventh with a translation
-    column scaled by 1e4), noisy and noise-free points.  The HIP kernel reproduces the host mirror
-    of its operation sequence to the last bit, and -- the check that matters -- satisfies the
-    reference's definition (LAPACK) and agrees with the JacobiSVD oracle up to sign."""
+    column scaled by 1e4), noisy and noise-free points.  The HIP kernel agrees with the host mirror
+    of its operation sequence to a few ulps times the conditioning, and -- the check that matters --
+    satisfies the reference's definition (LAPACK) and agrees with the JacobiSVD oracle up to sign."""
     from spectavi_amd import mvg
     rng = np.random.default_rng(77)
     worst = 0.0
@@ -253,19 +257,19 @@ def test_many_camera_pairs(oracle):
         xp = Xw @ P1.T + (k % 2) * rng.normal(0, 1e-3, (2003, 3))
         X = mvg.dlt_triangulate(P0, P1, x, xp)
         mX = oracle.dlt_mirror_triangulate(P0, P1, x, xp)
-        assert np.array_equal(np.isnan(X), np.isnan(mX))
-        worst = max(worst, float(np.nanmax(np.abs(X - mX))))
         e = mvg.dlt_reprojection_error(P0, P1, x, xp)
-        assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp), equal_nan=True)
+        worst = max(worst, dc.check_against_mirror(X, mX, P0, P1, x, xp, E=e,
+                                                   mE=oracle.dlt_mirror_reprojection_error(P0, P1, x, xp), what="pair %d" % k))
         dc.check_definition(X, P0, P1, x, xp, err=e, what="pair %d" % k)
         dc.check_against_oracle(X, oracle.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp, what="pair %d" % k)
-    assert worst == 0.0
+    assert worst < 1e-6
 
 
 def test_large_host_call_is_chunked_and_pipelined(oracle):
     """Results of 16 MB and more leave through the chunked upload / solve / download pipeline
     (pinned bounce buffers drained by host threads): 2 300 017 points = three chunks, the last one
-    ragged; fresh and reused output arrays; both entry points; bit for bit the mirror's rows."""
+    ragged; fresh and reused output arrays; both entry points; bit for bit the rows of one
+    device-resident launch over all points (and those within the mirror tolerance of the mirror's)."""
     from spectavi_amd import mvg
     from spectavi_amd.mvg import _dlt_triangulate
     rng = np.random.default_rng(41)
@@ -274,14 +278,20 @@ def test_large_host_call_is_chunked_and_pipelined(oracle):
     Xw = rng.standard_normal((npt, 4))
     x = Xw @ P0.T + rng.normal(0, 1e-3, (npt, 3))
     xp = Xw @ P1.T + rng.normal(0, 1e-3, (npt, 3))
-    want = oracle.dlt_mirror_triangulate(P0, P1, x, xp)
+    import torch
+    from spectavi_amd import device
+    dx, dxp = torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda()
+    want = device.dlt_triangulate(P0, P1, dx, dxp).cpu().numpy()   # one launch, no chunks, no host pipeline
     X = mvg.dlt_triangulate(P0, P1, x, xp)
     assert np.array_equal(X, want)
     dst = np.full((npt, 4), np.nan)
     _dlt_triangulate(P0, P1, npt, x, xp, dst)          # into an array that already has its pages
     assert np.array_equal(dst, want)
     e = mvg.dlt_reprojection_error(P0, P1, x, xp)       # 18 MB of errors: pipelined too
-    assert np.array_equal(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp))
+    assert np.array_equal(e.reshape(-1), device.dlt_reprojection_error(P0, P1, dx, dxp).cpu().numpy().reshape(-1))
+    sub0 = np.arange(0, npt, 23)
+    dc.check_against_mirror(X[sub0], oracle.dlt_mirror_triangulate(P0, P1, x[sub0], xp[sub0]), P0, P1, x[sub0], xp[sub0],
+                            E=e[sub0], mE=oracle.dlt_mirror_reprojection_error(P0, P1, x[sub0], xp[sub0]), what="large host call")
     sub = rng.integers(0, npt, 20000)
     dc.check_definition(X[sub], P0, P1, x[sub], xp[sub], err=e[sub], what="large host call")
 
@@ -290,7 +300,7 @@ def test_two_pass_scorer_paths_agree(oracle):
     """The RANSAC scorer defers the solves that do not converge on its fast path to a second kernel
     (work list in the caller's workspace).  Whatever the work list holds -- everything, the first few
     entries of an undersized one, or nothing (no workspace: all in place) -- counts and masks are the
-    same bits, and they are the host mirror's."""
+    same bits (and the host mirror's away from the threshold)."""
     import ctypes as ct
     import torch
     from spectavi_amd import device
@@ -304,9 +314,20 @@ def test_two_pass_scorer_paths_agree(oracle):
     xp[:, :2] += rng.normal(0, 2e-3, (npt, 2)) * xp[:, 2:3]
     xp[::4] = rng.standard_normal((len(xp[::4]), 3))
     P1s = np.stack(cams + [c + 0.05 * rng.standard_normal((3, 4)) for c in cams] + [rng.standard_normal((3, 4)) for _ in range(9)])
-    want_c, want_m = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, 1e-2)
     dP, dx, dxp = torch.from_numpy(P1s).cuda(), torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda()
     nh = P1s.shape[0]
+    # the reference for "same bits whatever the path": the one-pass form (no work list, every solve in place)
+    c1 = torch.zeros((nh,), dtype=torch.int32, device="cuda")
+    m1 = torch.zeros((nh, npt), dtype=torch.uint8, device="cuda")
+    check(clib.spv_dlt_score_hypotheses_device_ws(P0, dP.data_ptr(), nh, npt, dx.data_ptr(), dxp.data_ptr(), 1e-2,
+                                                  c1.data_ptr(), m1.data_ptr(), None, 0, None))
+    torch.cuda.synchronize()
+    want_c, want_m = c1.cpu().numpy(), m1.cpu().numpy().astype(bool)
+    # ... which agrees with the host mirror and with the oracle away from the threshold
+    mir_c, mir_m = oracle.dlt_mirror_score_hypotheses(P0, P1s, x, xp, 1e-2)
+    _, _, oerr = oracle.dlt_score_hypotheses(P0, P1s, x, xp, 1e-2, return_err=True)
+    clear = np.isfinite(oerr) & (np.abs(oerr - 1e-2) > 1e-11)
+    assert np.array_equal(want_m[clear], np.asarray(mir_m, bool)[clear])
     full = clib.spv_dlt_score_workspace_bytes(nh, npt)
     for ws_bytes in (full, 65536 + 8 * 1024 * 3, 65536 + 8 * 1024, 4096, 0):   # full list, 3 / 1 entries per shard, too small, none
         counts = torch.full((nh,), -7, dtype=torch.int32, device="cuda")
