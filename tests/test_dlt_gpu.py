@@ -34,7 +34,7 @@ def test_golden(golden):
     assert np.max(np.abs(X - sgn[:, None] * g["X"])) < 1e-12
     err = mvg.dlt_reprojection_error(g["P0"], g["P1"], g["x"], g["xp"])
     assert err.shape == (1000, 1)
-    assert np.max(np.abs(err - g["err_mirror"])) <= 1e-12 * max(1.0, float(np.max(g["err"])))
+    dc.check_against_mirror(X, g["X_mirror"], g["P0"], g["P1"], g["x"], g["xp"], E=err, mE=g["err_mirror"], what="golden")
     assert np.allclose(err, g["err"], rtol=1e-6, atol=1e-12)   # oracle, north_star's float tolerance
     dc.check_definition(X, g["P0"], g["P1"], g["x"], g["xp"], err=err, what="golden")
 
@@ -61,10 +61,10 @@ def test_batch_matches_oracle(oracle):
     x = Xw @ P0.T + rng.normal(0, 1e-3, (100003, 3))
     xp = Xw @ P1.T + rng.normal(0, 1e-3, (100003, 3))
     X = mvg.dlt_triangulate(P0, P1, x, xp)
-    assert np.max(np.abs(X - oracle.dlt_mirror_triangulate(P0, P1, x, xp))) <= RTOL
     assert np.max(np.abs(np.linalg.norm(X, axis=1) - 1)) < 1e-12 and np.all(X[:, 3] >= 0)
     e = mvg.dlt_reprojection_error(P0, P1, x, xp)
-    assert np.allclose(e, oracle.dlt_mirror_reprojection_error(P0, P1, x, xp), rtol=1e-12, atol=1e-15)
+    dc.check_against_mirror(X, oracle.dlt_mirror_triangulate(P0, P1, x, xp), P0, P1, x, xp, E=e,
+                            mE=oracle.dlt_mirror_reprojection_error(P0, P1, x, xp), what="batch")
     # the oracle (JacobiSVD restatement) and the LAPACK statement of the definition
     dc.check_against_oracle(X, oracle.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp)
     st = dc.check_definition(X, P0, P1, x, xp, err=e, what="batch")

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from tests import dlt_checks as dc
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -174,11 +176,13 @@ def test_in_library_rccl_gather_clique_of_one(oracle, rccl_gather):
     P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
     Xw = rng.standard_normal((10007, 4))
     X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
-    assert np.max(np.abs(X - oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
+    mX = oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
     oX = oracle.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
     assert np.max(np.abs(X - np.sign(np.einsum("ni,ni->n", X, oX))[:, None] * oX)) < 1e-9
     e = mvg.dlt_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T)
-    assert e.shape == (10007, 1) and np.allclose(e, oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T), rtol=1e-9, atol=1e-12)
+    assert e.shape == (10007, 1)
+    dc.check_against_mirror(X, mX, P0, P1, Xw @ P0.T, Xw @ P1.T, E=e,
+                            mE=oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T), what="clique of one")
     device.profile_enable(False)
     launches, ms = device.profile_read("gather")
     assert launches == 6 and ms > 0.0          # 2 x L1 + cascade records + cascade ncand + 2 x DLT
@@ -288,9 +292,9 @@ def test_gathered_layout_three_ranks(oracle, three_ranks_copy_transport):
     P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
     Xw = rng.standard_normal((10007, 4))
     X = mvg.dlt_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T)
-    assert np.max(np.abs(X - oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T))) <= 1e-12
     e = mvg.dlt_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T)
-    assert np.allclose(e, oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T), rtol=1e-9, atol=1e-12)
+    dc.check_against_mirror(X, oracle.dlt_mirror_triangulate(P0, P1, Xw @ P0.T, Xw @ P1.T), P0, P1, Xw @ P0.T, Xw @ P1.T, E=e,
+                            mE=oracle.dlt_mirror_reprojection_error(P0, P1, Xw @ P0.T, Xw @ P1.T), what="three ranks")
     device.profile_enable(False)
     assert device.profile_read("gather")[0] == 5 + 2 + 2    # five L1 calls, cascade records + ncand, two DLT calls
 

@@ -281,7 +281,10 @@ int main(int argc, char **argv) {
   const unsigned blocks = (unsigned)((npt + kDltThreads - 1) / kDltThreads);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](const char *name, auto launch) {
-    for (int i = 0; i < 20; i++) launch();
+    // warm up for ~0.3 s: the first launches after an idle period (the H2D copies above, the D2H
+    // copies of compare()) run at a lower clock state -- 20 launches (3 ms) were not enough and made
+    // whatever variant came first after a pause look 8 % slower than the identical code later on
+    for (int i = 0; i < 2000; i++) launch();
     hipDeviceSynchronize();
     hipEventRecord(e0);
     for (int i = 0; i < 200; i++) launch();
