@@ -93,8 +93,8 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
     uint32_t *__restrict__ codes,        // [n][nrows] sign codes
     uint32_t *__restrict__ masks,        // [n][nrows] (queries only)
     uint8_t *__restrict__ u8img,         // [nrows][dim]
-    uint32_t *__restrict__ counts,       // [n][nb+1] bucket histogram (database only, may be NULL)
-    uint32_t *__restrict__ ranks,        // [n][nrows] rank of the row inside its bucket (database only)
+    uint32_t *__restrict__ counts,       // [n][nb+1] bucket histogram (may be NULL: none wanted)
+    uint32_t *__restrict__ ranks,        // [n][nrows] rank of the row inside its bucket (with counts)
     uint32_t hbmask, int nb) {
   constexpr int R = kProjRows;
   __shared__ __attribute__((aligned(16))) uint8_t xs[kProjTile * kProjXStride];  // row tile, 16 dims
@@ -222,7 +222,9 @@ __global__ __launch_bounds__(kThreads) void project_kernel(
           codes[(size_t)j * nrows + r] = code;
           // database rows: bucket histogram for the counting sort, fused here
           // (the value the atomic returns is the row's rank inside its bucket: the fill pass
-          // needs no second round of atomics)
+          // needs no second round of atomics; the matrix-core kernels' epilogue does the same for
+          // query rows too, this kernel leaves those to query_rank_kernel: the atomic in this
+          // epilogue's query form cost its widest instantiation its full unrolling)
           if (!IS_QUERY && counts)
             ranks[(size_t)j * nrows + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
         }
@@ -350,7 +352,7 @@ __device__ __forceinline__ void project_rows_epilogue(
     }
     if (r < nrows) {
       codes[(size_t)j * nrows_total + r] = code;
-      if (!IS_QUERY && counts)
+      if (counts)
         ranks[(size_t)j * nrows_total + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
     }
     if (IS_QUERY) {
@@ -721,6 +723,18 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t *__restrict_
   if (e <= nb) c[e] = excl;
 }
 
+// Histogram + ranks of the QUERY sign codes, per table, for the VALU projection path (the
+// matrix-core epilogue has it fused): what the probe's query order is built from.
+__global__ __launch_bounds__(256) void query_rank_kernel(const uint32_t *__restrict__ codes, int N, int n,
+                                                         uint32_t hbmask, int nb, uint32_t *__restrict__ counts,
+                                                         uint32_t *__restrict__ ranks) {
+  const size_t total = (size_t)n * N;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = e / N;
+    ranks[e] = atomicAdd(&counts[j * (nb + 1) + (codes[e] & hbmask)], 1u);
+  }
+}
+
 __global__ void bucket_fill_kernel(const uint32_t *__restrict__ codes,
                                    const uint32_t *__restrict__ ranks, int M, int n, uint32_t hbmask,
                                    int nb, const uint32_t *__restrict__ bstart,
@@ -971,24 +985,44 @@ constexpr int kGroupCap = 256;  // candidate indices per group per window (32 gr
 __device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
 
+// Since round 3 the kernel runs once per table, over the queries in the order of THAT table's sign
+// code (counting sort fused into the query projection like the database's), with the query blocks
+// dealt so that the blocks sharing an XCD (b % 8 under the dispatcher's round-robin; speed only)
+// walk one contiguous eighth of the sorted order: the ~7.6 queries of a bucket, and the queries of
+// the buckets one low bit away, are then in flight together on one XCD and find that bucket's rows
+// in its L2 instead of gathering them again over the fabric (an L2 hit is ~2.5x cheaper than an
+// Infinity-Cache one, MI355X_MICROARCH.md).  Between the passes a query's two best keys and its
+// candidate count wait in `partial` / `pvisited`; the last pass writes the ABI outputs.  With
+// t_count = n and qorder = NULL it is the one-pass kernel of rounds 1-2 (small inputs, many tables).
+// Results do not depend on the order or the number of passes: the two smallest distinct keys.
 template <int CPL, int RU>
 __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
-    const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int n,
-    int g, int hb, const uint32_t *__restrict__ ysign, const uint32_t *__restrict__ ymask,
+    const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int t_first,
+    int t_count, int g, int hb, const uint32_t *__restrict__ ysign, const uint32_t *__restrict__ ymask,
     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ qorder,  // [N] queries in this pass's order, or NULL (identity)
+    int nblk, int per_xcd,                // query blocks; blocks per XCD range (0: block b takes slot block b)
+    uint64_t *__restrict__ partial, int32_t *__restrict__ pvisited, int first_pass, int last_pass,
     uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
   __shared__ uint32_t lists[kThreads / 8][kGroupCap];
   const int t = threadIdx.x;
   const int sub = t & 7;
-  const int query = blockIdx.x * (kThreads / 8) + (t >> 3);
-  const bool valid = query < N;
-  const int q = valid ? query : N - 1;  // keep every lane alive for the cross-lane ops
+  int slotblk = blockIdx.x;
+  if (per_xcd > 0) {
+    slotblk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (slotblk >= nblk) return;  // whole workgroup (nothing below synchronises across waves)
+  }
+  const int slot = slotblk * (kThreads / 8) + (t >> 3);
+  const bool valid = slot < N;
+  const int sq = valid ? slot : N - 1;  // keep every lane alive for the cross-lane ops
+  const int q = qorder ? (int)qorder[sq] : sq;
+  const int query = q;
   uint32_t *list = lists[t >> 3];
   const int nchunk = dim / 16;
   const uint32_t nb = 1u << hb;
   const uint32_t hbmask = nb - 1;
   const int nvar = 1 << g;
-  const int nprobe = n << g;
+  const int nprobe = t_count << g;
 
   uint4 qv[CPL];
 #pragma unroll
@@ -999,14 +1033,19 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
   }
   uint64_t k1 = kNone64, k2 = kNone64;
   int visited = 0;
+  if (!first_pass) {
+    k1 = partial[2 * (size_t)q];
+    k2 = partial[2 * (size_t)q + 1];
+    visited = pvisited[q];
+  }
 
   for (int p0 = 0; p0 < nprobe; p0 += 8) {
     // lane `sub` owns probe p0 + sub of this pass
     const int p = p0 + sub;
     uint32_t s = 0, len = 0;
-    int tj = 0;
+    int tj = t_first;
     if (p < nprobe) {
-      tj = p >> g;
+      tj = t_first + (p >> g);
       const uint32_t var = (uint32_t)(p & (nvar - 1));
       const uint32_t sg = ysign[(size_t)tj * N + q];
       const uint32_t mk = ymask[(size_t)tj * N + q];
@@ -1053,6 +1092,9 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
         for (int u = 0; u < RU; ++u) {
           live[u] = f0 + u < T;
           cand[u] = list[live[u] ? f0 + u : 0];
+          // a row that already holds one of the two best places (reached through another table or
+          // an earlier pass) would only reproduce its own key: do not gather it again
+          live[u] = live[u] && cand[u] != (uint32_t)k1 && cand[u] != (uint32_t)k2;
   #pragma unroll
           for (int c = 0; c < CPL; ++c) {
             const int ch = sub + 8 * c;
@@ -1087,7 +1129,11 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
   }
 
   if (valid && sub == 0) {
-    {
+    if (!last_pass) {
+      partial[2 * (size_t)query] = k1;
+      partial[2 * (size_t)query + 1] = k2;
+      pvisited[query] = visited;
+    } else {
       const bool n1 = k1 == kNone64, n2 = k2 == kNone64;
       out_idx[2 * (size_t)query + 0] = n1 ? ~0ull : (k1 & 0xFFFFFFFFull);
       out_idx[2 * (size_t)query + 1] = n2 ? ~0ull : (k2 & 0xFFFFFFFFull);
@@ -1101,7 +1147,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
 struct CascadeLayout {
   int mc, hb;
   size_t off_dictp, off_dictm, off_ux, off_uy, off_xcodes, off_ysign, off_ymask, off_bstart,
-      off_order, off_ranks, off_segsum, total;
+      off_order, off_ranks, off_segsum, off_qbstart, off_qorder, off_qranks, off_partial, off_pvisited, total;
 };
 
 CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
@@ -1126,6 +1172,13 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_ranks = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_segsum = take((size_t)n * ((nb1 + kScanSeg - 1) / kScanSeg) * sizeof(uint32_t));
+  // the probe's per-table query order (counting sort of the queries by sign code) and what a
+  // query carries from one table's pass to the next
+  L.off_qbstart = take((size_t)n * nb1 * sizeof(uint32_t));
+  L.off_qorder = take((size_t)n * yrows * sizeof(uint32_t));
+  L.off_qranks = take((size_t)n * yrows * sizeof(uint32_t));
+  L.off_partial = take((size_t)yrows * 2 * sizeof(uint64_t));
+  L.off_pvisited = take((size_t)yrows * sizeof(int32_t));
   L.total = off;
   return L;
 }
@@ -1295,7 +1348,29 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   const int nb = 1 << L.hb;
   const uint32_t hbmask = (uint32_t)nb - 1;
 
+  // The probe walks the queries table by table in the order of that table's sign code when the
+  // group kernel applies and the input is large enough for the order to matter (the per-table
+  // counting sorts and passes cost a dozen small launches); SPECTAVI_CASCADE_SORT=0 / 1 force it
+  // off / on (A/B runs, and the fuzz run covers both forms: same results).
+  const int sort_env = [] {  // read per call: tests switch it inside one process
+    const char *e = getenv("SPECTAVI_CASCADE_SORT");
+    return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1;
+  }();
+  static const bool group_env = [] {
+    const char *e = getenv("SPECTAVI_CASCADE_GROUP");
+    return !(e && e[0] == '0');
+  }();
+  const bool use_group = group_env && m <= L.hb && cpl <= 2;
+  const bool sorted = use_group && xrows > 0 &&
+                      (sort_env >= 0 ? sort_env == 1 : (n <= 8 && (long long)yrows >= 65536));
+  uint32_t *qbstart = reinterpret_cast<uint32_t *>(ws + L.off_qbstart);
+  uint32_t *qorder = reinterpret_cast<uint32_t *>(ws + L.off_qorder);
+  uint32_t *qranks = reinterpret_cast<uint32_t *>(ws + L.off_qranks);
+
   SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
+  if (sorted) SPV_HIP_CHECK(hipMemsetAsync(qbstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
+  uint32_t *qcounts = sorted ? qbstart : nullptr;
+  uint32_t *qrk = sorted ? qranks : nullptr;
   {
   ProfScope prof("cascade_project", stream);
   if (project_mfma_applies(m, n)) {
@@ -1305,7 +1380,7 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
                        m, nc);
     launch_project_mfma<false>(0, d_x, xrows, dim, m, n, dictm, xcodes, nullptr, ux, bstart, ranks, hbmask,
                                nb, stream);
-    launch_project_mfma<true>(g, d_y, yrows, dim, m, n, dictm, ysign, ymask, uy, nullptr, nullptr, hbmask,
+    launch_project_mfma<true>(g, d_y, yrows, dim, m, n, dictm, ysign, ymask, uy, qcounts, qrk, hbmask,
                               nb, stream);
   } else {
     hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
@@ -1314,6 +1389,9 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
                           nb, stream);
     launch_project<true>(L.mc, g, d_y, yrows, dim, m, n, dictp, ysign, ymask, uy, nullptr, nullptr, hbmask,
                          nb, stream);
+    if (sorted)
+      hipLaunchKernelGGL(query_rank_kernel, dim3(1024), dim3(256), 0, stream, ysign, yrows, n, hbmask, nb, qbstart,
+                         qranks);
   }
   }
   SPV_HIP_CHECK(hipGetLastError());
@@ -1330,6 +1408,15 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   if (xrows > 0)
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, ranks, xrows, n,
                        hbmask, nb, bstart, order);
+  if (sorted) {  // the queries' own counting sort, per table, by sign code
+    const int nseg = (nb + 1 + kScanSeg - 1) / kScanSeg;
+    uint32_t *segsum = reinterpret_cast<uint32_t *>(ws + L.off_segsum);  // the database's scan is done with it
+    hipLaunchKernelGGL(bucket_segsum_kernel, dim3(nseg, n), dim3(256), 0, stream, qbstart, nb, nseg, segsum);
+    hipLaunchKernelGGL(bucket_segscan_kernel, dim3(n), dim3(1024), 0, stream, segsum, nseg);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, n), dim3(1024), 0, stream, qbstart, nb, nseg, segsum);
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, ysign, qranks, yrows, n,
+                       hbmask, nb, qbstart, qorder);
+  }
   }
   SPV_HIP_CHECK(hipGetLastError());
 
@@ -1337,19 +1424,25 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   ProfScope prof_probe("cascade_probe_refine", stream);
   // group-per-query kernel unless the full-code check is needed (m > bucket bits) or rows
   // are wider than 256 bytes; otherwise the wave-per-query kernel
-  static const bool group_env = [] {
-    const char *e = getenv("SPECTAVI_CASCADE_GROUP");
-    return !(e && e[0] == '0');
-  }();
-  const bool use_group = group_env && m <= L.hb && cpl <= 2;
   if (use_group) {
-    const dim3 ggrid((yrows + kThreads / 8 - 1) / (kThreads / 8));
-    if (cpl == 1)
-      hipLaunchKernelGGL((probe_refine_group_kernel<1, 4>), ggrid, block, 0, stream, ux, uy, xrows,
-                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand);
-    else
-      hipLaunchKernelGGL((probe_refine_group_kernel<2, 2>), ggrid, block, 0, stream, ux, uy, xrows,
-                         yrows, dim, n, g, L.hb, ysign, ymask, bstart, order, d_idx, d_dist, d_ncand);
+    const int nblk = (yrows + kThreads / 8 - 1) / (kThreads / 8);
+    uint64_t *partial = reinterpret_cast<uint64_t *>(ws + L.off_partial);
+    int32_t *pvisited = reinterpret_cast<int32_t *>(ws + L.off_pvisited);
+    const int passes = sorted ? n : 1;
+    const int per_xcd = sorted ? (nblk + 7) / 8 : 0;
+    const dim3 ggrid(sorted ? 8 * per_xcd : nblk);
+    for (int ps = 0; ps < passes; ++ps) {
+      const int t_first = sorted ? ps : 0, t_count = sorted ? 1 : n;
+      const uint32_t *qo = sorted ? qorder + (size_t)ps * yrows : nullptr;
+      if (cpl == 1)
+        hipLaunchKernelGGL((probe_refine_group_kernel<1, 4>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim,
+                           t_first, t_count, g, L.hb, ysign, ymask, bstart, order, qo, nblk, per_xcd, partial,
+                           pvisited, ps == 0, ps == passes - 1, d_idx, d_dist, d_ncand);
+      else
+        hipLaunchKernelGGL((probe_refine_group_kernel<2, 2>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim,
+                           t_first, t_count, g, L.hb, ysign, ymask, bstart, order, qo, nblk, per_xcd, partial,
+                           pvisited, ps == 0, ps == passes - 1, d_idx, d_dist, d_ncand);
+    }
     SPV_HIP_CHECK(hipGetLastError());
     return SPV_OK;
   }

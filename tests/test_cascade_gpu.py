@@ -183,3 +183,38 @@ def test_full_size_properties_1m(oracle):
     assert np.array_equal(idx[sub].cpu().numpy().view(np.uint64), oidx)
     assert np.array_equal(dist[sub].cpu().numpy(), odist)
     assert np.array_equal(ncand[sub].cpu().numpy(), oncand)
+
+
+@pytest.mark.parametrize("m_rows,n_rows,dim,m,n,g", [
+    (5000, 3001, 128, 10, 2, 2),    # the default form (two tables, 8 probes), ragged last query block
+    (3000, 1000, 128, 6, 3, 0),     # no probing: one bucket per table, three passes
+    (4000, 517, 128, 3, 1, 1),      # one table, huge buckets: several list windows per pass
+    (2000, 33, 144, 8, 4, 3),       # 4 tables x 8 probes, dim 144 (two chunks per lane), fewer blocks than XCDs
+    (6000, 2500, 256, 9, 2, 4),     # 16 probes per table: two rounds of 8 inside a pass
+    (1000, 777, 144, 8, 16, 5),     # the reference test's parameters through 16 passes (VALU projection + query_rank_kernel)
+    (1, 300, 32, 4, 2, 1), (50, 1, 16, 4, 2, 2),
+])
+def test_sorted_probe_passes_match_oracle(oracle, monkeypatch, m_rows, n_rows, dim, m, n, g):
+    """The probe walks the queries table by table in the order of that table's sign code (large
+    inputs by default; SPECTAVI_CASCADE_SORT=1 forces it at any size, =0 forces the one-pass form).
+    Whatever the order and the number of passes, indices, distances and candidate counts are the
+    oracle's bits -- planted neighbours reached through several tables (the keys carried from pass to
+    pass, the skip of rows that already hold a place) included.  Reference:
+    src/CascadingHashNn.h:208-245."""
+    from spectavi_amd import feature
+    rng = np.random.default_rng([m_rows, n_rows, dim, m, n, g])
+    x = rng.integers(-128, 128, (m_rows, dim)).astype(np.float32)
+    y = rng.integers(-128, 128, (n_rows, dim)).astype(np.float32)
+    k = min(m_rows, n_rows) // 2
+    if k:
+        src = rng.integers(0, m_rows, k)
+        y[:k] = np.clip(x[src] + rng.integers(-1, 2, (k, dim)), -128, 127)
+        y[: k // 4] = x[src[: k // 4]]               # exact copies: distance 0 through every table
+    d = rng.standard_normal((n, dim, m)).astype(np.float32)
+    oidx, odist, oncand, _ = oracle.nn_cascading_hash(x, y, m, n, g, d)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SPECTAVI_CASCADE_SORT", mode)
+        idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+        assert np.array_equal(ncand, oncand), mode
+        assert np.array_equal(dist, odist), mode
+        assert np.array_equal(idx, oidx), mode
