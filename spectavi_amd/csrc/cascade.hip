@@ -977,10 +977,9 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
 // gathers ONE candidate row (8 lanes x 16 bytes = one 128-byte line, 8 different
 // queries' lines per wave instruction), v_sad_u8 + DPP sum, branch-free top-2.  All 8
 // lanes of a group hold the same keys, so no cross-lane merge is needed at the end.
-// A pass whose candidate stream is longer than kGroupCap entries is processed in several
+// A pass whose candidate stream is longer than CAP entries is processed in several
 // windows of the list.
 // ---------------------------------------------------------------------------------
-constexpr int kGroupCap = 256;  // candidate indices per group per window (32 groups -> 32 KB LDS)
 
 __device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
@@ -995,8 +994,8 @@ __device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a <
 // candidate count wait in `partial` / `pvisited`; the last pass writes the ABI outputs.  With
 // t_count = n and qorder = NULL it is the one-pass kernel of rounds 1-2 (small inputs, many tables).
 // Results do not depend on the order or the number of passes: the two smallest distinct keys.
-template <int CPL, int RU>
-__global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
+template <int CPL, int RU, int CAP, int WPE = 0>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void probe_refine_group_kernel(
     const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int t_first,
     int t_count, int g, int hb, const uint32_t *__restrict__ ysign, const uint32_t *__restrict__ ymask,
     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ order,
@@ -1004,7 +1003,7 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
     int nblk, int per_xcd,                // query blocks; blocks per XCD range (0: block b takes slot block b)
     uint64_t *__restrict__ partial, int32_t *__restrict__ pvisited, int first_pass, int last_pass,
     uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
-  __shared__ uint32_t lists[kThreads / 8][kGroupCap];
+  __shared__ uint32_t lists[kThreads / 8][CAP];
   const int t = threadIdx.x;
   const int sub = t & 7;
   int slotblk = blockIdx.x;
@@ -1064,10 +1063,10 @@ __global__ __launch_bounds__(kThreads) void probe_refine_group_kernel(
     const uint32_t total = __shfl(incl, 7, 8);
     const uint32_t excl = incl - len;
     visited += (int)total;
-    // the pass's candidate stream [0, total) is processed in windows of kGroupCap entries
+    // the pass's candidate stream [0, total) is processed in windows of CAP entries
     // (one window almost always; skewed buckets simply take more)
-    for (uint32_t w0 = 0; __any(w0 < total); w0 += kGroupCap) {
-      const uint32_t T = w0 < total ? min((uint32_t)kGroupCap, total - w0) : 0u;
+    for (uint32_t w0 = 0; __any(w0 < total); w0 += CAP) {
+      const uint32_t T = w0 < total ? min((uint32_t)CAP, total - w0) : 0u;
       // copy the window's part of every bucket: bucket b is broadcast from lane b, all 8
       // lanes copy it
       for (int b = 0; b < 8; ++b) {
@@ -1168,13 +1167,13 @@ CascadeLayout cascade_layout(int xrows, int yrows, int dim, int m, int n) {
   L.off_xcodes = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_ysign = take((size_t)n * yrows * sizeof(uint32_t));
   L.off_ymask = take((size_t)n * yrows * sizeof(uint32_t));
-  L.off_bstart = take((size_t)n * nb1 * sizeof(uint32_t));
+  L.off_bstart = take((size_t)2 * n * nb1 * sizeof(uint32_t));  // [n] database tables, then [n] query tables (one scan)
   L.off_order = take((size_t)n * xrows * sizeof(uint32_t));
   L.off_ranks = take((size_t)n * xrows * sizeof(uint32_t));
-  L.off_segsum = take((size_t)n * ((nb1 + kScanSeg - 1) / kScanSeg) * sizeof(uint32_t));
+  L.off_segsum = take((size_t)2 * n * ((nb1 + kScanSeg - 1) / kScanSeg) * sizeof(uint32_t));
   // the probe's per-table query order (counting sort of the queries by sign code) and what a
   // query carries from one table's pass to the next
-  L.off_qbstart = take((size_t)n * nb1 * sizeof(uint32_t));
+  L.off_qbstart = L.off_bstart + (size_t)n * nb1 * sizeof(uint32_t);
   L.off_qorder = take((size_t)n * yrows * sizeof(uint32_t));
   L.off_qranks = take((size_t)n * yrows * sizeof(uint32_t));
   L.off_partial = take((size_t)yrows * 2 * sizeof(uint64_t));
@@ -1367,10 +1366,16 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   uint32_t *qorder = reinterpret_cast<uint32_t *>(ws + L.off_qorder);
   uint32_t *qranks = reinterpret_cast<uint32_t *>(ws + L.off_qranks);
 
-  SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
-  if (sorted) SPV_HIP_CHECK(hipMemsetAsync(qbstart, 0, (size_t)n * (nb + 1) * sizeof(uint32_t), stream));
-  uint32_t *qcounts = sorted ? qbstart : nullptr;
-  uint32_t *qrk = sorted ? qranks : nullptr;
+  SPV_HIP_CHECK(hipMemsetAsync(bstart, 0, (size_t)(sorted ? 2 : 1) * n * (nb + 1) * sizeof(uint32_t), stream));
+  // query histogram + ranks: fused into the matrix-core projection's epilogue (+0.05 ms on the query
+  // pass at 1M rows: every wave ends on the round trip of its returning atomics) or, with
+  // SPECTAVI_CASCADE_QHIST=0 and always on the VALU path, a kernel of their own after it (+0.10 ms)
+  static const bool qhist_fused = [] {
+    const char *e = getenv("SPECTAVI_CASCADE_QHIST");
+    return !(e && e[0] == '0');
+  }();
+  uint32_t *qcounts = sorted && qhist_fused ? qbstart : nullptr;
+  uint32_t *qrk = sorted && qhist_fused ? qranks : nullptr;
   {
   ProfScope prof("cascade_project", stream);
   if (project_mfma_applies(m, n)) {
@@ -1382,6 +1387,9 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
                                nb, stream);
     launch_project_mfma<true>(g, d_y, yrows, dim, m, n, dictm, ysign, ymask, uy, qcounts, qrk, hbmask,
                               nb, stream);
+    if (sorted && !qhist_fused)
+      hipLaunchKernelGGL(query_rank_kernel, dim3(1024), dim3(256), 0, stream, ysign, yrows, n, hbmask, nb, qbstart,
+                         qranks);
   } else {
     hipLaunchKernelGGL(repack_dict_kernel, dim3(64), dim3(kThreads), 0, stream, d_dict, dictp, n, dim,
                        m, L.mc);
@@ -1399,24 +1407,20 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
   {
   ProfScope prof("cascade_buckets", stream);
   {
+    // database and (sorted probe) query histograms sit back to back: one scan over 2n "tables"
     const int nseg = (nb + 1 + kScanSeg - 1) / kScanSeg;
+    const int ntab = sorted ? 2 * n : n;
     uint32_t *segsum = reinterpret_cast<uint32_t *>(ws + L.off_segsum);
-    hipLaunchKernelGGL(bucket_segsum_kernel, dim3(nseg, n), dim3(256), 0, stream, bstart, nb, nseg, segsum);
-    hipLaunchKernelGGL(bucket_segscan_kernel, dim3(n), dim3(1024), 0, stream, segsum, nseg);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, n), dim3(1024), 0, stream, bstart, nb, nseg, segsum);
+    hipLaunchKernelGGL(bucket_segsum_kernel, dim3(nseg, ntab), dim3(256), 0, stream, bstart, nb, nseg, segsum);
+    hipLaunchKernelGGL(bucket_segscan_kernel, dim3(ntab), dim3(1024), 0, stream, segsum, nseg);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, ntab), dim3(1024), 0, stream, bstart, nb, nseg, segsum);
   }
   if (xrows > 0)
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, xcodes, ranks, xrows, n,
                        hbmask, nb, bstart, order);
-  if (sorted) {  // the queries' own counting sort, per table, by sign code
-    const int nseg = (nb + 1 + kScanSeg - 1) / kScanSeg;
-    uint32_t *segsum = reinterpret_cast<uint32_t *>(ws + L.off_segsum);  // the database's scan is done with it
-    hipLaunchKernelGGL(bucket_segsum_kernel, dim3(nseg, n), dim3(256), 0, stream, qbstart, nb, nseg, segsum);
-    hipLaunchKernelGGL(bucket_segscan_kernel, dim3(n), dim3(1024), 0, stream, segsum, nseg);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(nseg, n), dim3(1024), 0, stream, qbstart, nb, nseg, segsum);
+  if (sorted)  // the queries' own order, per table, by sign code
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, ysign, qranks, yrows, n,
                        hbmask, nb, qbstart, qorder);
-  }
   }
   SPV_HIP_CHECK(hipGetLastError());
 
@@ -1434,14 +1438,30 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     for (int ps = 0; ps < passes; ++ps) {
       const int t_first = sorted ? ps : 0, t_count = sorted ? 1 : n;
       const uint32_t *qo = sorted ? qorder + (size_t)ps * yrows : nullptr;
-      if (cpl == 1)
-        hipLaunchKernelGGL((probe_refine_group_kernel<1, 4>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim,
-                           t_first, t_count, g, L.hb, ysign, ymask, bstart, order, qo, nblk, per_xcd, partial,
-                           pvisited, ps == 0, ps == passes - 1, d_idx, d_dist, d_ncand);
-      else
-        hipLaunchKernelGGL((probe_refine_group_kernel<2, 2>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim,
-                           t_first, t_count, g, L.hb, ysign, ymask, bstart, order, qo, nblk, per_xcd, partial,
-                           pvisited, ps == 0, ps == passes - 1, d_idx, d_dist, d_ncand);
+#define SPV_LAUNCH_GROUP(C, U, CAPV, ...)                                                                     \
+  hipLaunchKernelGGL((probe_refine_group_kernel<C, U, CAPV, ##__VA_ARGS__>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim, \
+                     t_first, t_count, g, L.hb, ysign, ymask, bstart, order, qo, nblk, per_xcd, partial,        \
+                     pvisited, ps == 0, ps == passes - 1, d_idx, d_dist, d_ncand)
+      // <rows per lane group, gathers in flight per group, list window, waves per SIMD>.  Measured at
+      // 1M x 1M, sorted passes (profiles/r03_cascade_variants.txt): <1,4,256> (rounds 1-2: 32 KB of LDS
+      // per workgroup = 5 waves per SIMD) 1.90 ms; <1,4,128> (16 KB, 65 VGPRs: 7 waves) 1.33; <1,8,128>
+      // 1.50; <1,6,128> 1.39; <1,4,128,8> (64 VGPRs + one spilled dword: 8 waves) 1.29; <1,3,128,8> 1.30:
+      // once the rows come out of the XCD's L2 the kernel is bound by its chain of dependent loads
+      // (order -> signs -> bucket bounds -> bucket entries -> rows), i.e. by waves in flight.
+      // SPECTAVI_CASCADE_GV=1 selects the 7-wave form (A/B runs).
+      static const int gv_env = [] {
+        const char *e = getenv("SPECTAVI_CASCADE_GV");
+        return e ? atoi(e) : 0;
+      }();
+      if (cpl == 1) {
+        if (gv_env == 1)
+          SPV_LAUNCH_GROUP(1, 4, 128);
+        else
+          SPV_LAUNCH_GROUP(1, 4, 128, 8);
+      } else {
+        SPV_LAUNCH_GROUP(2, 2, 128);
+      }
+#undef SPV_LAUNCH_GROUP
     }
     SPV_HIP_CHECK(hipGetLastError());
     return SPV_OK;
