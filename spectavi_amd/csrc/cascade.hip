@@ -352,6 +352,11 @@ __device__ __forceinline__ void project_rows_epilogue(
     }
     if (r < nrows) {
       codes[(size_t)j * nrows_total + r] = code;
+      // bucket histogram, fused (database rows: the buckets; query rows: the order the probe walks
+      // them in); the value the atomic returns is the row's rank inside its bucket, so the fill pass
+      // needs no second round of atomics.  (Issuing the atomics of all tables together after this
+      // loop, one round trip per wave instead of one per table, measured 0.385 -> 0.405 ms for the
+      // 1M + 1M rows of the sorted form, no change for the database pass alone: kept per table.)
       if (counts)
         ranks[(size_t)j * nrows_total + r] = atomicAdd(&counts[(size_t)j * (nb + 1) + (code & hbmask)], 1u);
     }
@@ -513,7 +518,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CT <= 
 // 4x4x1 A operand); the left-over hyperplanes sit in a workgroup-shared LDS table [dim/4][4][4].
 // workgroups per CU by LDS (4 wave tiles + the left-over table): three for the default shape
 constexpr int mfma4_waves_per_simd(int ct, int ng) {
-  return 4 * 64 * 4 * (16 * ct + 4 * ng + 1 > 36 ? 16 * ct + 4 * ng + 1 : 36) + ng * 8192 <= 160 * 1024 / 3 ? 3 : 2;
+  // wave tiles + uint8 staging (static) + the left-over table at its largest (dim 512, dynamic)
+  return 4 * 64 * 4 * (16 * ct + 4 * ng + 1 > 36 ? 16 * ct + 4 * ng + 1 : 36) + 4 * 2048 + ng * 8192 <= 160 * 1024 / 3 ? 3 : 2;
 }
 
 template <int CT, int NG, bool IS_QUERY, int GMAX>
@@ -529,20 +535,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(mfma4_
   constexpr int XS = kMfmaChunk + 4;     // floats per staged row: 16-byte aligned rows
   constexpr int ES = NCOL + 1;           // floats per row of the transposed projections
   constexpr int kWaveFloats = 64 * (ES > XS ? ES : XS);
-  constexpr int kMaxDim = 512;
   __shared__ __attribute__((aligned(16))) float lds[(kThreads / 64) * kWaveFloats];
-  __shared__ __attribute__((aligned(16))) float hl[NG][kMaxDim / 4][4][4];  // [group][k / 4][column][k % 4]
+  // uint8 image of the chunk being staged, per wave: 64 rows x 32 bytes, written one packed dword per
+  // lane and load (byte offset 256 j + 4 lane = row-major) and read back 16 bytes per lane for the
+  // stores.  Round 2 assembled those 16 bytes with four quad broadcasts and a predicated copy per
+  // load: 80 VALU instructions per chunk, a fifth of the database pass's.
+  __shared__ __attribute__((aligned(16))) uint32_t u8s[kThreads / 64][64 * kMfmaChunk / 4];
+  // left-over hyperplanes [group][k / 4][column][k % 4], sized by the launch: NG * dim * 16 bytes
+  // (8 KB per group at dim 512, 2 KB at 128: statically sized for 512 they cost dim 128 its third
+  // workgroup per CU once the uint8 staging above was added)
+  extern __shared__ __attribute__((aligned(16))) float hl_dyn[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float *ws = lds + wv * kWaveFloats;
-  // left-over hyperplanes -> LDS (whole workgroup; the only workgroup-level step)
-  for (int e = threadIdx.x; e < NG * dim * 4; e += kThreads) {
-    const int gq = e / (dim * 4), rem = e - gq * dim * 4;
-    const int k = rem >> 2, j = rem & 3;
-    hl[gq][k >> 2][j][k & 3] = dictm[(size_t)k * NCD + 16 * CT + 4 * gq + j];
-  }
-  __syncthreads();
+  uint32_t *u8w = u8s[wv];
+  const int hl_group = dim * 4;  // floats per group
   const long long row0 = ((long long)blockIdx.x * (kThreads / 64) + wv) * 64;
-  if (row0 >= nrows) return;  // whole wave past the end (nothing below synchronises across waves)
   const int r16 = lane & 15, q4 = lane >> 4;
   const int quad = lane & 3;
 
@@ -574,40 +581,47 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(mfma4_
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) bq[ks][ct] = dictm[(size_t)(c0 + 4 * ks + q4) * NCD + 16 * ct + r16];
   };
+  // left-over hyperplanes -> LDS (whole workgroup; the only workgroup-level step).  (Requesting the
+  // wave's first row chunk BEFORE this staging was tried: __syncthreads() waits for vmcnt(0), so the
+  // HBM round trip moved in front of the barrier instead of under it: 0.385 -> 0.41 ms.)
+  for (int e = threadIdx.x; e < NG * dim * 4; e += kThreads) {
+    const int gq = e / (dim * 4), rem = e - gq * dim * 4;
+    const int k = rem >> 2, j = rem & 3;
+    hl_dyn[gq * hl_group + ((k >> 2) * 4 + j) * 4 + (k & 3)] = dictm[(size_t)k * NCD + 16 * CT + 4 * gq + j];
+  }
+  __syncthreads();
+  if (row0 >= nrows) return;  // whole wave past the end (nothing below synchronises across waves)
   prefetch(0);
   fetch_b_chunk(0);
   for (int c0 = 0; c0 < dim; c0 += kMfmaChunk) {
-    uint4 keep = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int e = lane + 64 * j;
       const int row = e >> 3, part = e & 7;
       const float4 v = px[j];
       *reinterpret_cast<float4 *>(ws + row * XS + 4 * part) = v;
-      const uint32_t pk = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
-      const uint32_t g0 = __builtin_amdgcn_mov_dpp(pk, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
-      const uint32_t g1 = __builtin_amdgcn_mov_dpp(pk, 0x55, 0xF, 0xF, true);  // [1,1,1,1]
-      const uint32_t g2 = __builtin_amdgcn_mov_dpp(pk, 0xAA, 0xF, 0xF, true);  // [2,2,2,2]
-      const uint32_t g3 = __builtin_amdgcn_mov_dpp(pk, 0xFF, 0xF, 0xF, true);  // [3,3,3,3]
-      if (quad == (j & 3)) keep = make_uint4(g0, g1, g2, g3);
-      if ((j & 3) == 3) {
-        const int krow = 8 * ((j & ~3) + quad) + (lane >> 3);  // row of the load this lane kept
-        const int kbyte = c0 + 16 * ((lane & 7) >> 2);         // first byte of the quad's 16
-        if (row0 + krow < nrows)
-          *reinterpret_cast<uint4 *>(u8img + (size_t)(row0 + krow) * dim + kbyte) = keep;
-      }
+      // row (lane >> 3) + 8 j, bytes 4 (lane & 7) .. +3 of its 32: dword 64 j + lane of the image
+      u8w[64 * j + lane] = f2u8(v.x) | (f2u8(v.y) << 8) | (f2u8(v.z) << 16) | (f2u8(v.w) << 24);
     }
     if (c0 + kMfmaChunk < dim) prefetch(c0 + kMfmaChunk);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the chunk's uint8 image out: 16-byte piece p = lane + 64 k is half (p & 1) of row p >> 1
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int piece = lane + 64 * k;
+      const uint4 img = *reinterpret_cast<const uint4 *>(u8w + 4 * piece);
+      if (row0 + (piece >> 1) < nrows)
+        *reinterpret_cast<uint4 *>(u8img + (size_t)(row0 + (piece >> 1)) * dim + c0 + 16 * (piece & 1)) = img;
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       // left-over columns first in program order (any order is fine: separate accumulators)
       const float4 al = *reinterpret_cast<const float4 *>(ws + lane * XS + 4 * ks);  // row = lane, 4 consecutive k
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
-        const float4 bl = *reinterpret_cast<const float4 *>(&hl[gq][(c0 >> 2) + ks][quad][0]);
+        const float4 bl = *reinterpret_cast<const float4 *>(hl_dyn + gq * hl_group + (((c0 >> 2) + ks) * 4 + quad) * 4);
         accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.x, bl.x, accl[gq], 0, 0, 0);
         accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.y, bl.y, accl[gq], 0, 0, 0);
         accl[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(al.z, bl.z, accl[gq], 0, 0, 0);
@@ -1259,10 +1273,12 @@ void launch_project_mfma(int g, const float *rows, int nrows, int dim, int m, in
     if (!off4 && full && dim <= 512 && left >= 1 && left <= 8) {
 #define SPV_LAUNCH_M4(CTV, NGV)                                                                        \
   if (g <= G0)                                                                                         \
-    hipLaunchKernelGGL((project_mfma4_kernel<CTV, NGV, IS_QUERY, G0>), grid, block, 0, stream, rows,   \
+    hipLaunchKernelGGL((project_mfma4_kernel<CTV, NGV, IS_QUERY, G0>), grid, block,                    \
+                       (size_t)(NGV) * dim * 16, stream, rows,                                         \
                        nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb);      \
   else                                                                                                 \
-    hipLaunchKernelGGL((project_mfma4_kernel<CTV, NGV, IS_QUERY, G2>), grid, block, 0, stream, rows,   \
+    hipLaunchKernelGGL((project_mfma4_kernel<CTV, NGV, IS_QUERY, G2>), grid, block,                    \
+                       (size_t)(NGV) * dim * 16, stream, rows,                                         \
                        nrows, dim, m, n, g, dictm, codes, masks, img, counts, ranks, hbmask, nb)
       switch (ctm * 2 + (ng - 1)) {
         case 0: SPV_LAUNCH_M4(0, 1); break;
