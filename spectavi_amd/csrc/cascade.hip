@@ -20,12 +20,14 @@
 //                     + uint8 image
 //   4 bucket_segsum / segscan / scan, 5 bucket_fill   counting sort of database
 //                     indices by bucket = code & (2^HB - 1), per table
-//   6 probe_refine_group   one 8-lane group per query (8 queries per wave): 2^g probe
-//                     codes per table (src/CascadingHashNn.h:170-179) -> bucket ranges ->
-//                     the group's candidate list in LDS -> per round each group gathers
-//                     one 128-byte candidate row (8 different queries' lines per wave
-//                     instruction), v_sad_u8 + DPP reduce, branch-free two smallest
-//                     (dist, idx) keys
+//   6 probe_table     one launch per table, one 8-lane group per query (8 queries per wave), the
+//                     queries walked in the order of that table's sign code (a second counting
+//                     sort, large inputs only) so that a bucket's rows stay in the XCD's L2: 2^g
+//                     probe codes (src/CascadingHashNn.h:170-179) -> bucket ranges -> the group's
+//                     candidate list in LDS -> per round each group gathers one 128-byte
+//                     candidate row (8 different queries' lines per wave instruction), v_sad_u8 +
+//                     DPP reduce, branch-free two smallest (dist, idx) keys carried from table
+//                     to table
 //   7 probe_refine    one wave per query (the first design, issue-bound): used when
 //                     kernel 6 does not apply -- full-code check (m > 22) or rows wider
 //                     than 256 bytes (up to 2048)
@@ -983,41 +985,72 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
 
 
 // ---------------------------------------------------------------------------------
-// 7b. group-per-query probe + refine: one 8-lane group per query, 8 queries per wave,
-// 32 per workgroup.  The one-wave-per-query kernel above spends ~1100 wave instructions
-// per query and is issue-bound; here every wave instruction serves 8 queries: lane s of a
-// group owns probe s of each pass of 8 probes (the default n * 2^g is exactly 8), the
-// group copies its buckets into a private LDS list, and in every round each group
-// gathers ONE candidate row (8 lanes x 16 bytes = one 128-byte line, 8 different
-// queries' lines per wave instruction), v_sad_u8 + DPP sum, branch-free top-2.  All 8
-// lanes of a group hold the same keys, so no cross-lane merge is needed at the end.
-// A pass whose candidate stream is longer than CAP entries is processed in several
-// windows of the list.
+// 7b. group-per-query probe + refine, one table per launch: one 8-lane group per query, 8 queries
+// per wave, 32 per workgroup.  The one-wave-per-query kernel above spends ~1100 wave instructions
+// per query and is issue-bound; here every wave instruction serves 8 queries: lane s of a group owns
+// probe s of each round of 8 probes (the default 2^g is 4), the group lays the probed buckets'
+// entries out in a private LDS list, and in every round each group gathers ONE candidate row
+// (8 lanes x 16 bytes = one 128-byte line, 8 different queries' lines per wave instruction),
+// v_sad_u8 + DPP sum, branch-free top-2.  All 8 lanes of a group hold the same keys, so no
+// cross-lane merge is needed at the end.  A round whose candidate stream is longer than 128
+// entries is processed in several windows of the list.
+//
+// Round 3: the kernel runs once per TABLE, over the queries in the order of that table's sign code
+// (counting sort fused into the query projection like the database's), with the query blocks dealt
+// so that the blocks sharing an XCD (b % 8 under the dispatcher's round-robin; speed only) walk one
+// contiguous eighth of the sorted order: the ~7.6 queries of a bucket, and the queries of the
+// buckets one low bit away, are then in flight together on one XCD and find that bucket's rows in
+// its L2 instead of gathering them again over the fabric (1M x 1M: FETCH_SIZE 13.3 -> 3.7 GB per
+// step, L2 hit rate 5 -> 60 %, profiles/r03_cascade_pmc.md).  Between the passes a query's two best
+// keys and its candidate count wait in `partial` / `pvisited`; the last pass writes the ABI outputs.
+// Small inputs skip the sort (qorder = NULL, input order) but still go table by table.  Results do
+// not depend on the order of the queries or of the tables: the two smallest distinct keys.
+//
+// That made the kernel issue-bound (SQ_INSTS_VALU 2 800 per wave and pass = 0.57 of the pass's
+// 0.64 ms), so the instruction count per candidate went from ~54 to ~30:
+//   * keys ordered by v_min_f64 / v_max_f64: a key (distance << 32 | index) is a positive double
+//     whose order is the integer order of its bits (distances < 2^20: denormals, which the f64 units
+//     keep), "none" = the largest finite double; the top-2 network is 3 instructions instead of
+//     3 x (v_cmp_u64 + 2 v_cndmask) + hazard nops;
+//   * "same row again" (a row reached through an earlier table, or twice when nan projections
+//     leave a query with fewer than g probe bits) is a 32-bit index comparison with the two kept rows
+//     at insertion instead of two 64-bit key comparisons;
+//   * the candidate list of a round of probes is filled flat: list position p finds its bucket by a
+//     packed byte comparison against the 8 bucket offsets (4 instructions) and loads its entry, four
+//     independent loads per lane in flight -- rounds 1-2 walked the buckets one by one, one dependent
+//     global load per 8 entries, every one of those round trips serial;
+//   * four list entries per ds_read_b128; row addresses as a uniform base + 32-bit shifted offset
+//     (dim a power of two, the image below 4 GiB) instead of two v_mad_u64_u32 per row; unconditional
+//     loads (row 0 / entry 0 for the slots past the end) instead of an exec-mask branch per load.
 // ---------------------------------------------------------------------------------
+constexpr uint64_t kNoneD = 0x7FEFFFFFFFFFFFFFull;
 
-__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+__device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (uint64_t)__double_as_longlong(r);
+}
+__device__ __forceinline__ uint64_t key_max(uint64_t a, uint64_t b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (uint64_t)__double_as_longlong(r);
+}
 
-// Since round 3 the kernel runs once per table, over the queries in the order of THAT table's sign
-// code (counting sort fused into the query projection like the database's), with the query blocks
-// dealt so that the blocks sharing an XCD (b % 8 under the dispatcher's round-robin; speed only)
-// walk one contiguous eighth of the sorted order: the ~7.6 queries of a bucket, and the queries of
-// the buckets one low bit away, are then in flight together on one XCD and find that bucket's rows
-// in its L2 instead of gathering them again over the fabric (an L2 hit is ~2.5x cheaper than an
-// Infinity-Cache one, MI355X_MICROARCH.md).  Between the passes a query's two best keys and its
-// candidate count wait in `partial` / `pvisited`; the last pass writes the ABI outputs.  With
-// t_count = n and qorder = NULL it is the one-pass kernel of rounds 1-2 (small inputs, many tables).
-// Results do not depend on the order or the number of passes: the two smallest distinct keys.
-template <int CPL, int RU, int CAP, int WPE = 0>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void probe_refine_group_kernel(
-    const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int t_first,
-    int t_count, int g, int hb, const uint32_t *__restrict__ ysign, const uint32_t *__restrict__ ymask,
-    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ order,
+template <int CPL, int RU, int WPE, bool SHIFT, bool FULL>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void probe_table_kernel(
+    const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int dshift, int g, int hb,
+    const uint32_t *__restrict__ ysign,   // [N] sign codes of THIS table
+    const uint32_t *__restrict__ ymask,   // [N]
+    const uint32_t *__restrict__ bstart,  // [2^hb + 1] bucket offsets of this table
+    const uint32_t *__restrict__ order,   // [M] database rows grouped by bucket
     const uint32_t *__restrict__ qorder,  // [N] queries in this pass's order, or NULL (identity)
     int nblk, int per_xcd,                // query blocks; blocks per XCD range (0: block b takes slot block b)
     uint64_t *__restrict__ partial, int32_t *__restrict__ pvisited, int first_pass, int last_pass,
     uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
-  __shared__ uint32_t lists[kThreads / 8][CAP];
+  constexpr int CAP = 128;
+  static_assert(RU == 4, "four list entries per ds_read_b128");
+  __shared__ __attribute__((aligned(16))) uint32_t lists[kThreads / 8][CAP];
+  __shared__ __attribute__((aligned(16))) uint32_t gtab[kThreads / 8][16];  // [0..7] bucket offsets, [8..15] start - offset
   const int t = threadIdx.x;
   const int sub = t & 7;
   int slotblk = blockIdx.x;
@@ -1029,13 +1062,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? 
   const bool valid = slot < N;
   const int sq = valid ? slot : N - 1;  // keep every lane alive for the cross-lane ops
   const int q = qorder ? (int)qorder[sq] : sq;
-  const int query = q;
   uint32_t *list = lists[t >> 3];
+  uint32_t *tab = gtab[t >> 3];
   const int nchunk = dim / 16;
-  const uint32_t nb = 1u << hb;
-  const uint32_t hbmask = nb - 1;
+  const uint32_t hbmask = (1u << hb) - 1;
   const int nvar = 1 << g;
-  const int nprobe = t_count << g;
 
   uint4 qv[CPL];
 #pragma unroll
@@ -1044,7 +1075,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? 
     qv[c] = ch < nchunk ? *reinterpret_cast<const uint4 *>(uy + (size_t)q * dim + 16 * ch)
                         : make_uint4(0, 0, 0, 0);
   }
-  uint64_t k1 = kNone64, k2 = kNone64;
+  const uint32_t sg = ysign[q], mk = ymask[q];
+  uint64_t k1 = kNoneD, k2 = kNoneD;
   int visited = 0;
   if (!first_pass) {
     k1 = partial[2 * (size_t)q];
@@ -1052,22 +1084,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? 
     visited = pvisited[q];
   }
 
-  for (int p0 = 0; p0 < nprobe; p0 += 8) {
-    // lane `sub` owns probe p0 + sub of this pass
+  for (int p0 = 0; p0 < nvar; p0 += 8) {
+    // lane `sub` owns probe p0 + sub of this round
     const int p = p0 + sub;
     uint32_t s = 0, len = 0;
-    int tj = t_first;
-    if (p < nprobe) {
-      tj = t_first + (p >> g);
-      const uint32_t var = (uint32_t)(p & (nvar - 1));
-      const uint32_t sg = ysign[(size_t)tj * N + q];
-      const uint32_t mk = ymask[(size_t)tj * N + q];
-      const uint32_t pcode = (sg & ~mk) | deposit_bits(var, mk);
-      const uint32_t *bs = bstart + (size_t)tj * (nb + 1) + (pcode & hbmask);
+    if (p < nvar) {
+      const uint32_t pcode = (sg & ~mk) | deposit_bits((uint32_t)p, mk);
+      const uint32_t *bs = bstart + (pcode & hbmask);
       s = bs[0];
       len = bs[1] - s;
     }
-    // exclusive offsets of the 8 buckets inside the group's list
+    // exclusive offsets of the 8 buckets inside the round's candidate stream
     uint32_t incl = len;
 #pragma unroll
     for (int d = 1; d < 8; d <<= 1) {
@@ -1077,49 +1104,69 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? 
     const uint32_t total = __shfl(incl, 7, 8);
     const uint32_t excl = incl - len;
     visited += (int)total;
-    // the pass's candidate stream [0, total) is processed in windows of CAP entries
-    // (one window almost always; skewed buckets simply take more)
+    tab[sub] = excl;
+    tab[8 + sub] = s - excl;  // entry of stream position x of this bucket: order[x + (s - excl)]
+    __builtin_amdgcn_wave_barrier();
+    // the stream [0, total) is processed in windows of CAP entries (one almost always)
     for (uint32_t w0 = 0; __any(w0 < total); w0 += CAP) {
       const uint32_t T = w0 < total ? min((uint32_t)CAP, total - w0) : 0u;
-      // copy the window's part of every bucket: bucket b is broadcast from lane b, all 8
-      // lanes copy it
-      for (int b = 0; b < 8; ++b) {
-        const uint32_t bl = __shfl(len, b, 8);
-        const uint32_t bs_ = __shfl(s, b, 8);
-        const uint32_t bo = __shfl(excl, b, 8);
-        const int bj = __shfl(tj, b, 8);
-        const uint32_t *src = order + (size_t)bj * M + bs_;
-        // entries e of the bucket sit at stream positions bo + e; keep those inside the window
-        const uint32_t e_lo = w0 > bo ? w0 - bo : 0u;
-        const uint32_t e_hi = bo + bl > w0 + T ? (w0 + T > bo ? w0 + T - bo : 0u) : bl;
-        for (uint32_t e = (e_lo & ~7u) + sub; e < e_hi; e += 8)
-          if (e >= e_lo) list[bo + e - w0] = src[e];
+      // bucket offsets relative to the window, clamped to [0, 128], one byte each
+      uint32_t thrA, thrB;
+      {
+        const uint4 ea = *reinterpret_cast<const uint4 *>(tab), eb = *reinterpret_cast<const uint4 *>(tab + 4);
+        auto rel = [&](uint32_t e) { return (uint32_t)min(max((int)(e - w0), 0), 128); };
+        thrA = rel(ea.x) | (rel(ea.y) << 8) | (rel(ea.z) << 16) | (rel(ea.w) << 24);
+        thrB = rel(eb.x) | (rel(eb.y) << 8) | (rel(eb.z) << 16) | (rel(eb.w) << 24);
+      }
+      for (int it = 0; it < 4; ++it) {  // 32 list positions per step, four independent loads per lane
+        if (!__any(T > 32u * it)) break;
+        uint32_t ent[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t pos = (uint32_t)sub + 8u * (4 * it + i);  // < 128
+          // bucket of position pos: the last one whose offset is <= pos.  Per byte, bit 7 of
+          // 0x80 + pos - offset is set iff offset <= pos (pos <= 127, offset <= 128: no borrow)
+          const uint32_t rep = (pos * 0x01010101u) | 0x80808080u;
+          const uint32_t cnt = __builtin_popcount((rep - thrA) & 0x80808080u) + __builtin_popcount((rep - thrB) & 0x80808080u);
+          const uint32_t delta = tab[8 + ((cnt - 1) & 7)];
+          // unconditional load (entry 0 for the positions past the end): no exec-mask branch per entry
+          ent[i] = order[pos < T ? delta + w0 + pos : 0u];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) list[sub + 8 * (4 * it + i)] = ent[i];
       }
       __builtin_amdgcn_wave_barrier();
       // rounds: one candidate row per group per round, RU rounds in flight
       for (uint32_t f0 = 0; __any(f0 < T); f0 += RU) {
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(list + (f0 < T ? f0 : 0u));
+        const uint32_t cand[RU] = {c4.x, c4.y, c4.z, c4.w};
         uint4 xv[RU][CPL];
-        uint32_t cand[RU];
         bool live[RU];
-  #pragma unroll
+#pragma unroll
         for (int u = 0; u < RU; ++u) {
           live[u] = f0 + u < T;
-          cand[u] = list[live[u] ? f0 + u : 0];
-          // a row that already holds one of the two best places (reached through another table or
-          // an earlier pass) would only reproduce its own key: do not gather it again
-          live[u] = live[u] && cand[u] != (uint32_t)k1 && cand[u] != (uint32_t)k2;
-  #pragma unroll
+          // the slots past the end of the list gather row 0 (unconditional loads: no exec-mask branch
+          // per row; at most RU - 1 such rows per window, L2 hits) and are dropped at insertion
+          const uint32_t row = live[u] ? cand[u] : 0u;
+#pragma unroll
           for (int c = 0; c < CPL; ++c) {
+            // FULL: the row fills all 8 * CPL chunks (dim 128, 256); otherwise the lanes past the row's
+            // end re-read its last chunk and are zeroed (their query chunk is zero too)
             const int ch = sub + 8 * c;
-            xv[u][c] = make_uint4(0, 0, 0, 0);
-            if (live[u] && ch < nchunk)
-              xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)cand[u] * dim + 16 * ch);
+            const int chc = FULL ? ch : min(ch, nchunk - 1);
+            if (SHIFT) {
+              const uint32_t off = (row << dshift) + 16u * (uint32_t)chc;
+              xv[u][c] = *reinterpret_cast<const uint4 *>(ux + off);
+            } else {
+              xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)row * dim + 16 * chc);
+            }
+            if (!FULL && ch >= nchunk) xv[u][c] = make_uint4(0, 0, 0, 0);
           }
         }
-  #pragma unroll
+#pragma unroll
         for (int u = 0; u < RU; ++u) {
           uint32_t d = 0;
-  #pragma unroll
+#pragma unroll
           for (int c = 0; c < CPL; ++c) {
             d = sad_u8(qv[c].x, xv[u][c].x, d);
             d = sad_u8(qv[c].y, xv[u][c].y, d);
@@ -1127,13 +1174,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? 
             d = sad_u8(qv[c].w, xv[u][c].w, d);
           }
           d = group8_sum(d);
-          // branch-free insertion of a key that may repeat (same row reached via another table)
-          uint64_t k = ((uint64_t)d << 32) | cand[u];
-          const bool skip = !live[u] || k == k1 || k == k2;
-          k = skip ? kNone64 : k;
-          const uint64_t hi = max_u64(k, k1);
-          k1 = min_u64(k, k1);
-          k2 = min_u64(hi, k2);
+          // a row that already holds a place (an earlier table's pass, or a bucket probed twice)
+          // would only repeat its own key
+          const bool dead = !live[u] || cand[u] == (uint32_t)k1 || cand[u] == (uint32_t)k2;
+          const uint64_t k = dead ? kNoneD : (((uint64_t)d << 32) | cand[u]);
+          const uint64_t hi = key_max(k, k1);
+          k1 = key_min(k, k1);
+          k2 = key_min(hi, k2);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1143,16 +1190,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE ? 
 
   if (valid && sub == 0) {
     if (!last_pass) {
-      partial[2 * (size_t)query] = k1;
-      partial[2 * (size_t)query + 1] = k2;
-      pvisited[query] = visited;
+      partial[2 * (size_t)q] = k1;
+      partial[2 * (size_t)q + 1] = k2;
+      pvisited[q] = visited;
     } else {
-      const bool n1 = k1 == kNone64, n2 = k2 == kNone64;
-      out_idx[2 * (size_t)query + 0] = n1 ? ~0ull : (k1 & 0xFFFFFFFFull);
-      out_idx[2 * (size_t)query + 1] = n2 ? ~0ull : (k2 & 0xFFFFFFFFull);
-      out_dist[2 * (size_t)query + 0] = n1 ? 2147483648.0f : (float)(uint32_t)(k1 >> 32);
-      out_dist[2 * (size_t)query + 1] = n2 ? 2147483648.0f : (float)(uint32_t)(k2 >> 32);
-      if (out_ncand) out_ncand[query] = visited;
+      const bool n1 = k1 == kNoneD, n2 = k2 == kNoneD;
+      out_idx[2 * (size_t)q + 0] = n1 ? ~0ull : (k1 & 0xFFFFFFFFull);
+      out_idx[2 * (size_t)q + 1] = n2 ? ~0ull : (k2 & 0xFFFFFFFFull);
+      out_dist[2 * (size_t)q + 0] = n1 ? 2147483648.0f : (float)(uint32_t)(k1 >> 32);
+      out_dist[2 * (size_t)q + 1] = n2 ? 2147483648.0f : (float)(uint32_t)(k2 >> 32);
+      if (out_ncand) out_ncand[q] = visited;
     }
   }
 }
@@ -1448,39 +1495,38 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
     const int nblk = (yrows + kThreads / 8 - 1) / (kThreads / 8);
     uint64_t *partial = reinterpret_cast<uint64_t *>(ws + L.off_partial);
     int32_t *pvisited = reinterpret_cast<int32_t *>(ws + L.off_pvisited);
-    const int passes = sorted ? n : 1;
     const int per_xcd = sorted ? (nblk + 7) / 8 : 0;
     const dim3 ggrid(sorted ? 8 * per_xcd : nblk);
-    for (int ps = 0; ps < passes; ++ps) {
-      const int t_first = sorted ? ps : 0, t_count = sorted ? 1 : n;
-      const uint32_t *qo = sorted ? qorder + (size_t)ps * yrows : nullptr;
-#define SPV_LAUNCH_GROUP(C, U, CAPV, ...)                                                                     \
-  hipLaunchKernelGGL((probe_refine_group_kernel<C, U, CAPV, ##__VA_ARGS__>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim, \
-                     t_first, t_count, g, L.hb, ysign, ymask, bstart, order, qo, nblk, per_xcd, partial,        \
-                     pvisited, ps == 0, ps == passes - 1, d_idx, d_dist, d_ncand)
-      // <rows per lane group, gathers in flight per group, list window, waves per SIMD>.  Measured at
-      // 1M x 1M, sorted passes (profiles/r03_cascade_variants.txt): <1,4,256> (rounds 1-2: 32 KB of LDS
-      // per workgroup = 5 waves per SIMD) 1.90 ms; <1,4,128> (16 KB, 65 VGPRs: 7 waves) 1.33; <1,8,128>
-      // 1.50; <1,6,128> 1.39; <1,4,128,8> (64 VGPRs + one spilled dword: 8 waves) 1.29; <1,3,128,8> 1.30:
-      // once the rows come out of the XCD's L2 the kernel is bound by its chain of dependent loads
-      // (order -> signs -> bucket bounds -> bucket entries -> rows), i.e. by waves in flight.
-      // SPECTAVI_CASCADE_GV=1 selects the 7-wave form (A/B runs).
-      static const int gv_env = [] {
-        const char *e = getenv("SPECTAVI_CASCADE_GV");
-        return e ? atoi(e) : 0;
-      }();
-      if (cpl == 1) {
-        if (gv_env == 1)
-          SPV_LAUNCH_GROUP(1, 4, 128);
-        else
-          SPV_LAUNCH_GROUP(1, 4, 128, 8);
-      } else {
-        SPV_LAUNCH_GROUP(2, 2, 128);
+    {
+      int dshift = 0;
+      while ((1 << dshift) < dim) ++dshift;
+      const bool shift = (1 << dshift) == dim && (unsigned long long)xrows * (unsigned)dim < (1ull << 32);
+      const int nb1 = nb + 1;
+      for (int ps = 0; ps < n; ++ps) {
+        const uint32_t *qo = sorted ? qorder + (size_t)ps * yrows : nullptr;
+#define SPV_LAUNCH_LEAN(C, W, S, F)                                                                                   \
+  hipLaunchKernelGGL((probe_table_kernel<C, 4, W, S, F>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim, dshift, \
+                     g, L.hb, ysign + (size_t)ps * yrows, ymask + (size_t)ps * yrows, bstart + (size_t)ps * nb1,   \
+                     order + (size_t)ps * xrows, qo, nblk, per_xcd, partial, pvisited, ps == 0, ps == n - 1,       \
+                     d_idx, d_dist, d_ncand)
+        if (cpl == 1) {
+          // waves per SIMD: the kernel wants 88 VGPRs; capped at 80 / 72 / 64 (6 / 7 / 8 waves) it spills
+          // 8 / 12 / 16 dwords inside the gather loop and measured 1.23 / 1.21 / 1.24 ms per 1M queries
+          // against 1.11 ms with five unspilled waves (profiles/r03_cascade_variants.txt)
+          if (shift && dim == 128)
+            SPV_LAUNCH_LEAN(1, 5, true, true);     // SIFT-128, the benchmark's shape
+          else if (shift)
+            SPV_LAUNCH_LEAN(1, 5, true, false);    // dim 16, 32, 64
+          else
+            SPV_LAUNCH_LEAN(1, 5, false, false);   // dim 48, 80, 96, 112, or an image of 4 GiB and more
+        } else {
+          SPV_LAUNCH_LEAN(2, 4, false, false);     // dim 144 .. 256
+        }
+#undef SPV_LAUNCH_LEAN
       }
-#undef SPV_LAUNCH_GROUP
+      SPV_HIP_CHECK(hipGetLastError());
+      return SPV_OK;
     }
-    SPV_HIP_CHECK(hipGetLastError());
-    return SPV_OK;
   }
   const dim3 pgrid(grid.x);
 #define SPV_LAUNCH_PROBE(C, U)                                                                       \
