@@ -62,7 +62,15 @@ def fuzz_cascade(seed, budget, only_case=None):
         d = rng.standard_normal((nt, dim, m)).astype(np.float32)
         if rng.random() < 0.2:
             d = np.round(d)                            # integer hyperplanes: exact-zero projections
+        # the probe's query order: library default (input order at these sizes), forced per-table
+        # sign-code order, forced input order -- read per call, same results
+        mode = (None, "1", "0")[n % 3]
+        if mode is None:
+            os.environ.pop("SPECTAVI_CASCADE_SORT", None)
+        else:
+            os.environ["SPECTAVI_CASCADE_SORT"] = mode
         idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+        os.environ.pop("SPECTAVI_CASCADE_SORT", None)
         oi, od, onc, _ = o.nn_cascading_hash(x, y, m, nt, g, d)
         if not (np.array_equal(ncand, onc) and np.array_equal(dist, od) and np.array_equal(idx, oi)):
             bad = np.flatnonzero((ncand != onc) | (dist != od).any(1) | (idx != oi).any(1))
