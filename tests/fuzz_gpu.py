@@ -420,5 +420,7 @@ if __name__ == "__main__":
         if name == "pipeline":
             print("pipeline: %d random scenes, device-resident == host front-end (to rounding), both consistent with the scene" % cases, flush=True)
             continue
-        print("%s: %d random cases %s the oracle" % (name, cases, "agree with" if name in ("seven_point", "ransac_fit")
-                                                       else "bit-identical to"), flush=True)
+        how = {"seven_point": "agree with", "ransac_fit": "agree with",
+               "dlt": "within tolerance of the LAPACK definition, the JacobiSVD oracle (up to sign) and the host mirror; decisions as",
+               "score": "decide as (away from the threshold)"}.get(name, "bit-identical to")
+        print("%s: %d random cases %s the oracle" % (name, cases, how), flush=True)
