@@ -1118,6 +1118,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, W
         thrA = rel(ea.x) | (rel(ea.y) << 8) | (rel(ea.z) << 16) | (rel(ea.w) << 24);
         thrB = rel(eb.x) | (rel(eb.y) << 8) | (rel(eb.z) << 16) | (rel(eb.w) << 24);
       }
+      // (not unrolled: unrolled, the sixteen lane-constant positions and their byte-replicated forms
+      // were hoisted out of every loop and held 31 VGPRs through the gather loop -- 88 in all, five
+      // waves per SIMD)
+#pragma unroll 1
       for (int it = 0; it < 4; ++it) {  // 32 list positions per step, four independent loads per lane
         if (!__any(T > 32u * it)) break;
         uint32_t ent[4];
@@ -1510,17 +1514,18 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
                      order + (size_t)ps * xrows, qo, nblk, per_xcd, partial, pvisited, ps == 0, ps == n - 1,       \
                      d_idx, d_dist, d_ncand)
         if (cpl == 1) {
-          // waves per SIMD: the kernel wants 88 VGPRs; capped at 80 / 72 / 64 (6 / 7 / 8 waves) it spills
-          // 8 / 12 / 16 dwords inside the gather loop and measured 1.23 / 1.21 / 1.24 ms per 1M queries
-          // against 1.11 ms with five unspilled waves (profiles/r03_cascade_variants.txt)
+          // waves per SIMD: 59 VGPRs and 18 KB of LDS per workgroup = eight waves.  (A first build
+          // wanted 88 VGPRs -- the list fill's unrolled lane constants, see the kernel -- and measured
+          // 1.11 ms per 1M queries at five unspilled waves, 1.21-1.24 spilling at 6-8:
+          // profiles/r03_cascade_variants.txt)
           if (shift && dim == 128)
-            SPV_LAUNCH_LEAN(1, 5, true, true);     // SIFT-128, the benchmark's shape
+            SPV_LAUNCH_LEAN(1, 8, true, true);     // SIFT-128, the benchmark's shape
           else if (shift)
-            SPV_LAUNCH_LEAN(1, 5, true, false);    // dim 16, 32, 64
+            SPV_LAUNCH_LEAN(1, 8, true, false);    // dim 16, 32, 64
           else
-            SPV_LAUNCH_LEAN(1, 5, false, false);   // dim 48, 80, 96, 112, or an image of 4 GiB and more
+            SPV_LAUNCH_LEAN(1, 8, false, false);   // dim 48, 80, 96, 112, or an image of 4 GiB and more
         } else {
-          SPV_LAUNCH_LEAN(2, 4, false, false);     // dim 144 .. 256
+          SPV_LAUNCH_LEAN(2, 6, false, false);     // dim 144 .. 256 (80 VGPRs)
         }
 #undef SPV_LAUNCH_LEAN
       }
