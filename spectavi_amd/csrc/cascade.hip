@@ -1021,7 +1021,12 @@ __global__ __launch_bounds__(kThreads) void probe_refine_kernel(
 //     global load per 8 entries, every one of those round trips serial;
 //   * four list entries per ds_read_b128; row addresses as a uniform base + 32-bit shifted offset
 //     (dim a power of two, the image below 4 GiB) instead of two v_mad_u64_u32 per row; unconditional
-//     loads (row 0 / entry 0 for the slots past the end) instead of an exec-mask branch per load.
+//     loads (row 0 / entry 0 for the slots past the end) instead of an exec-mask branch per load;
+//   * RU = 8 (rows of up to 128 bytes): eight rows in flight per group, and instead of all eight lanes
+//     reducing every candidate's eight partial sums (3 DPP adds each) a transposing butterfly leaves
+//     lane s with the whole sum of candidate s (7 DPP adds + 14 selects per 8 candidates); each lane
+//     keeps the best two of ITS candidates, the eight pairs are merged once at the end of the pass
+//     (equal keys = the same row, counted once).  ~12 instructions per candidate.
 // ---------------------------------------------------------------------------------
 constexpr uint64_t kNoneD = 0x7FEFFFFFFFFFFFFFull;
 
@@ -1036,6 +1041,20 @@ __device__ __forceinline__ uint64_t key_max(uint64_t a, uint64_t b) {
   return (uint64_t)__double_as_longlong(r);
 }
 
+// (k1 <= k2) of this lane and of the lane CTRL pairs it with -> the two smallest distinct keys of the four
+template <int CTRL>
+__device__ __forceinline__ void merge_keys_with(uint64_t &k1, uint64_t &k2) {
+  const uint64_t o1 = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k1 >> 32), CTRL, 0xF, 0xF, true) << 32) |
+                      (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k1, CTRL, 0xF, 0xF, true);
+  const uint64_t o2 = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k2 >> 32), CTRL, 0xF, 0xF, true) << 32) |
+                      (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k2, CTRL, 0xF, 0xF, true);
+  const uint64_t lo = key_min(k1, o1);
+  uint64_t mid = key_max(k1, o1);
+  if (mid == lo) mid = kNoneD;
+  k2 = key_min(mid, key_min(k2, o2));
+  k1 = lo;
+}
+
 template <int CPL, int RU, int WPE, bool SHIFT, bool FULL>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void probe_table_kernel(
     const uint8_t *__restrict__ ux, const uint8_t *__restrict__ uy, int M, int N, int dim, int dshift, int g, int hb,
@@ -1048,7 +1067,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, W
     uint64_t *__restrict__ partial, int32_t *__restrict__ pvisited, int first_pass, int last_pass,
     uint64_t *__restrict__ out_idx, float *__restrict__ out_dist, int32_t *__restrict__ out_ncand) {
   constexpr int CAP = 128;
-  static_assert(RU == 4, "four list entries per ds_read_b128");
+  static_assert(RU == 4 || RU == 8, "list entries come four per ds_read_b128");
   __shared__ __attribute__((aligned(16))) uint32_t lists[kThreads / 8][CAP];
   __shared__ __attribute__((aligned(16))) uint32_t gtab[kThreads / 8][16];  // [0..7] bucket offsets, [8..15] start - offset
   const int t = threadIdx.x;
@@ -1140,6 +1159,69 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, W
         for (int i = 0; i < 4; ++i) list[sub + 8 * (4 * it + i)] = ent[i];
       }
       __builtin_amdgcn_wave_barrier();
+      if constexpr (RU == 8) {
+        // Eight candidate rows per round; afterwards lane s of the group OWNS candidate s: the eight
+        // partial sums of the eight lanes are reduced by a transposing butterfly (7 DPP adds + 14
+        // selects per 8 candidates instead of 3 DPP adds per candidate), and the top-2 update runs once
+        // per lane and round on that lane's candidate.  The lanes' pairs are merged after the last round.
+        const bool up4 = (sub & 4) != 0, up2 = (sub & 2) != 0, up1 = (sub & 1) != 0;
+        for (uint32_t f0 = 0; __any(f0 < T); f0 += 8) {
+          const uint32_t fb = f0 < T ? f0 : 0u;
+          const uint4 ca = *reinterpret_cast<const uint4 *>(list + fb);
+          const uint4 cb = *reinterpret_cast<const uint4 *>(list + fb + 4);
+          const uint32_t cand[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+          const uint32_t mine = list[fb + sub];
+          uint4 xv[8][CPL];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t row = f0 + u < T ? cand[u] : 0u;  // slots past the end gather row 0, dropped below
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const int ch = sub + 8 * c;
+              const int chc = FULL ? ch : min(ch, nchunk - 1);
+              if (SHIFT) {
+                const uint32_t off = (row << dshift) + 16u * (uint32_t)chc;
+                xv[u][c] = *reinterpret_cast<const uint4 *>(ux + off);
+              } else {
+                xv[u][c] = *reinterpret_cast<const uint4 *>(ux + (size_t)row * dim + 16 * chc);
+              }
+              if (!FULL && ch >= nchunk) xv[u][c] = make_uint4(0, 0, 0, 0);
+            }
+          }
+          uint32_t d[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            d[u] = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              d[u] = sad_u8(qv[c].x, xv[u][c].x, d[u]);
+              d[u] = sad_u8(qv[c].y, xv[u][c].y, d[u]);
+              d[u] = sad_u8(qv[c].z, xv[u][c].z, d[u]);
+              d[u] = sad_u8(qv[c].w, xv[u][c].w, d[u]);
+            }
+          }
+          // lanes i and 7 - i exchange halves (upper lanes keep candidates 4..7), then i and i ^ 2, then
+          // i and i ^ 1: lane i ends with the whole sum of candidate i
+          uint32_t e[4], f[2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t keep = up4 ? d[j + 4] : d[j], send = up4 ? d[j] : d[j + 4];
+            e[j] = keep + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x141 /*row_half_mirror*/, 0xF, 0xF, true);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t keep = up2 ? e[j + 2] : e[j], send = up2 ? e[j] : e[j + 2];
+            f[j] = keep + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true);
+          }
+          const uint32_t keep = up1 ? f[1] : f[0], send = up1 ? f[0] : f[1];
+          const uint32_t dsum = keep + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+          const bool dead = !(f0 + (uint32_t)sub < T) || mine == (uint32_t)k1 || mine == (uint32_t)k2;
+          const uint64_t k = dead ? kNoneD : (((uint64_t)dsum << 32) | mine);
+          const uint64_t hi = key_max(k, k1);
+          k1 = key_min(k, k1);
+          k2 = key_min(hi, k2);
+        }
+      } else
       // rounds: one candidate row per group per round, RU rounds in flight
       for (uint32_t f0 = 0; __any(f0 < T); f0 += RU) {
         const uint4 c4 = *reinterpret_cast<const uint4 *>(list + (f0 < T ? f0 : 0u));
@@ -1192,6 +1274,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, W
     __builtin_amdgcn_wave_barrier();
   }
 
+  if constexpr (RU == 8) {
+    // the eight lanes' pairs -> the group's pair (every lane ends with it).  Equal keys are the same
+    // row (the carried pair every lane started from, a row met again): counted once.
+    merge_keys_with<0x141>(k1, k2);  // i <-> 7 - i
+    merge_keys_with<0x4E>(k1, k2);   // i <-> i ^ 2
+    merge_keys_with<0xB1>(k1, k2);   // i <-> i ^ 1
+  }
   if (valid && sub == 0) {
     if (!last_pass) {
       partial[2 * (size_t)q] = k1;
@@ -1508,8 +1597,10 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
       const int nb1 = nb + 1;
       for (int ps = 0; ps < n; ++ps) {
         const uint32_t *qo = sorted ? qorder + (size_t)ps * yrows : nullptr;
-#define SPV_LAUNCH_LEAN(C, W, S, F)                                                                                   \
-  hipLaunchKernelGGL((probe_table_kernel<C, 4, W, S, F>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim, dshift, \
+#define SPV_RU(...) SPV_RU_(__VA_ARGS__ __VA_OPT__(,) 4)
+#define SPV_RU_(A, ...) A
+#define SPV_LAUNCH_LEAN(C, W, S, F, ...)                                                                              \
+  hipLaunchKernelGGL((probe_table_kernel<C, SPV_RU(__VA_ARGS__), W, S, F>), ggrid, block, 0, stream, ux, uy, xrows, yrows, dim, dshift, \
                      g, L.hb, ysign + (size_t)ps * yrows, ymask + (size_t)ps * yrows, bstart + (size_t)ps * nb1,   \
                      order + (size_t)ps * xrows, qo, nblk, per_xcd, partial, pvisited, ps == 0, ps == n - 1,       \
                      d_idx, d_dist, d_ncand)
@@ -1518,16 +1609,32 @@ int cascade_run(const float *d_x, const float *d_y, int xrows, int yrows, int di
           // wanted 88 VGPRs -- the list fill's unrolled lane constants, see the kernel -- and measured
           // 1.11 ms per 1M queries at five unspilled waves, 1.21-1.24 spilling at 6-8:
           // profiles/r03_cascade_variants.txt)
-          if (shift && dim == 128)
-            SPV_LAUNCH_LEAN(1, 8, true, true);     // SIFT-128, the benchmark's shape
+          // rows of up to 128 bytes: eight rows in flight per group, lane s owning candidate s after the
+          // transposing reduce (69 VGPRs, seven waves): 0.90 ms per 1M queries against 0.98 for four rows
+          // in flight with every lane reducing every candidate (59 VGPRs, eight waves);
+          // SPECTAVI_CASCADE_RU8=0 selects the latter (A/B runs)
+          const bool ru4_env = [] {  // read per call: the tests run both forms in one process
+            const char *e = getenv("SPECTAVI_CASCADE_RU8");
+            return e && e[0] == '0';
+          }();
+          if (ru4_env) {
+            if (shift && dim == 128)
+              SPV_LAUNCH_LEAN(1, 8, true, true);
+            else if (shift)
+              SPV_LAUNCH_LEAN(1, 8, true, false);
+            else
+              SPV_LAUNCH_LEAN(1, 8, false, false);
+          } else if (shift && dim == 128)
+            SPV_LAUNCH_LEAN(1, 7, true, true, 8);     // SIFT-128, the benchmark's shape
           else if (shift)
-            SPV_LAUNCH_LEAN(1, 8, true, false);    // dim 16, 32, 64
+            SPV_LAUNCH_LEAN(1, 7, true, false, 8);    // dim 16, 32, 64
           else
-            SPV_LAUNCH_LEAN(1, 8, false, false);   // dim 48, 80, 96, 112, or an image of 4 GiB and more
+            SPV_LAUNCH_LEAN(1, 7, false, false, 8);   // dim 48, 80, 96, 112, or an image of 4 GiB and more
         } else {
           SPV_LAUNCH_LEAN(2, 6, false, false);     // dim 144 .. 256 (80 VGPRs)
         }
 #undef SPV_LAUNCH_LEAN
+#undef SPV_RU
       }
       SPV_HIP_CHECK(hipGetLastError());
       return SPV_OK;

@@ -214,7 +214,12 @@ def test_sorted_probe_passes_match_oracle(oracle, monkeypatch, m_rows, n_rows, d
     oidx, odist, oncand, _ = oracle.nn_cascading_hash(x, y, m, n, g, d)
     for mode in ("1", "0"):
         monkeypatch.setenv("SPECTAVI_CASCADE_SORT", mode)
-        idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
-        assert np.array_equal(ncand, oncand), mode
-        assert np.array_equal(dist, odist), mode
-        assert np.array_equal(idx, oidx), mode
+        for ru8 in (None, "0"):   # eight rows per round with a candidate per lane (default) / four, every lane reducing all
+            if ru8 is None:
+                monkeypatch.delenv("SPECTAVI_CASCADE_RU8", raising=False)
+            else:
+                monkeypatch.setenv("SPECTAVI_CASCADE_RU8", ru8)
+            idx, dist, ncand = feature.nn_cascading_hash_with_dict(x, y, d, g=g, return_ncand=True)
+            assert np.array_equal(ncand, oncand), (mode, ru8)
+            assert np.array_equal(dist, odist), (mode, ru8)
+            assert np.array_equal(idx, oidx), (mode, ru8)
