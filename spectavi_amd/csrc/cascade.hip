@@ -577,11 +577,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(mfma4_
   // operands of the 16-column tiles for a whole chunk, requested ahead of the next row prefetch
   // (see project_mfma_kernel)
   float bq[KS][CT > 0 ? CT : 1];
+  // one per-lane base pointer, the (k-step, tile) offsets as immediates: the sixteen separately
+  // indexed loads of round 2 kept sixteen 64-bit addresses (32 VGPRs) alive across the chunk loop
+  const float *bp = dictm + (size_t)q4 * NCD + r16;
   auto fetch_b_chunk = [&](int c0) {
+    const float *bc = bp + (size_t)c0 * NCD;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) bq[ks][ct] = dictm[(size_t)(c0 + 4 * ks + q4) * NCD + 16 * ct + r16];
+      for (int ct = 0; ct < CT; ++ct) bq[ks][ct] = bc[4 * ks * NCD + 16 * ct];
   };
   // left-over hyperplanes -> LDS (whole workgroup; the only workgroup-level step).  (Requesting the
   // wave's first row chunk BEFORE this staging was tried: __syncthreads() waits for vmcnt(0), so the
