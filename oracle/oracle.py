@@ -96,7 +96,23 @@ def lib():
 
 
 def max_threads():
-    return int(lib().oracle_max_threads())
+    """Host threads OpenMP would use by default (captured at load time: set_threads changes the team size)."""
+    global _max_threads
+    if _max_threads is None:
+        _max_threads = int(lib().oracle_max_threads())
+    return _max_threads
+
+
+_max_threads = None
+
+
+def set_threads(n):
+    """Team size of the oracle's parallel regions that take no explicit count (the cascade)."""
+    max_threads()
+    L = lib()
+    L.oracle_set_threads.restype = None
+    L.oracle_set_threads.argtypes = [ct.c_int]
+    L.oracle_set_threads(int(n))
 
 
 def nn_bruteforcel1k2(x, y, nthreads=1):

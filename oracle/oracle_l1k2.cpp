@@ -119,4 +119,14 @@ int oracle_max_threads(void) {
 #endif
 }
 
+// OpenMP team size of the parallel regions that take no explicit count (oracle_cascade.cpp): the
+// CPU-baseline table runs the cascade at the reference's hard-wired 8 threads and at all of them.
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 }  // extern "C"

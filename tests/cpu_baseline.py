@@ -28,27 +28,30 @@ def l1k2(xrows, dim, threads, target_s=6.0):
             "pairs_per_s": nq * xrows / dt}
 
 
-def cascade(rows=1_000_000, sample=4096):
+def cascade(rows=1_000_000, queries=1_000_000):
     """the cascade restatement (oracle_cascade.cpp: hashing + bucket build over the
-    full database, then probe + L1 refine) on a query subsample against the full 1M-row database, m=17,
-    n=2, g=2 (the Python front-end's defaults at this size); setup and per-query time reported apart,
-    the 1M-query figure extrapolated linearly and labelled so."""
+    full database, then probe + L1 refine) at BASELINE configs[2] in full -- 1M x 1M, m=17, n=2, g=2 (the
+    Python front-end's defaults at this size) -- at the reference's hard-wired 8 threads
+    (src/CascadingHashNn.h:230) and at all host threads; the setup (one query) is reported beside it."""
     rng = np.random.default_rng(0xdeadbeef)
     x = (rng.integers(0, 256, (rows, 128), dtype=np.uint8).astype(np.float32) - 128)
-    y = (rng.integers(0, 256, (sample, 128), dtype=np.uint8).astype(np.float32) - 128)
+    y = (rng.integers(0, 256, (queries, 128), dtype=np.uint8).astype(np.float32) - 128)
     d = np.random.default_rng(0x5eed).standard_normal((2, 128, 17)).astype(np.float32)
-    o.nn_cascading_hash(x, y[:1], 17, 2, 2, d)           # warm-up: threads, page faults
-    t0 = time.perf_counter()
-    o.nn_cascading_hash(x, y[:1], 17, 2, 2, d)           # one query: the setup (codes + buckets) dominates
-    setup = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    _, _, ncand, _ = o.nn_cascading_hash(x, y, 17, 2, 2, d)
-    full = time.perf_counter() - t0
-    per_query = max(full - setup, 1e-9) / sample
-    return {"path": "nn_cascading_hash (oracle_cascade.cpp, OpenMP over rows / queries as the reference's default 8 threads allow)",
-            "xrows": rows, "queries_sampled": sample, "threads": o.max_threads(), "setup_s": setup, "seconds": full,
-            "mean_candidates": float(ncand.mean()), "queries_per_s_after_setup": 1.0 / per_query,
-            "extrapolated_1m_queries_s": setup + per_query * 1_000_000, "extrapolated": True}
+    out = []
+    for threads in sorted({8, o.max_threads()}):
+        o.set_threads(threads)
+        o.nn_cascading_hash(x, y[:1], 17, 2, 2, d)           # warm-up: threads, page faults
+        t0 = time.perf_counter()
+        o.nn_cascading_hash(x, y[:1], 17, 2, 2, d)           # one query: the setup (codes + buckets)
+        setup = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, _, ncand, _ = o.nn_cascading_hash(x, y, 17, 2, 2, d)
+        full = time.perf_counter() - t0
+        out.append({"path": "nn_cascading_hash (oracle_cascade.cpp: codes + buckets + probe + L1 refine)", "xrows": rows,
+                    "queries": queries, "threads": threads, "setup_s": setup, "seconds": full,
+                    "mean_candidates": float(ncand.mean()), "queries_per_s": queries / full})
+    o.set_threads(o.max_threads())
+    return out
 
 
 def dlt(npt=1_000_000):
@@ -96,5 +99,6 @@ if __name__ == "__main__":
     for xrows in (1000, 262144, 1_000_000):
         for th in sorted({1, 8, allc}):
             print(json.dumps(l1k2(xrows, 128, th)), flush=True)
-    print(json.dumps(cascade()), flush=True)
+    for rec in cascade():
+        print(json.dumps(rec), flush=True)
     print(json.dumps(dlt()), flush=True)
