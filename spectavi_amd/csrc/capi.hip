@@ -1170,10 +1170,12 @@ int run_gathered(const std::vector<int> &all_devs, long long total, const std::v
   const int G = (int)std::min<long long>((long long)all_devs.size(), std::max<long long>(total, 1));
   const std::vector<int> devs(all_devs.begin(), all_devs.begin() + G);
   const size_t K = row_bytes.size();
+  // (decided before the clique lock is taken: the automatic rule may itself build a clique under it)
+  const bool want_rccl = (transport == SPV_GATHER_AUTO ? gather_transport(all_devs, total) : transport) == SPV_GATHER_RCCL;
   std::lock_guard<std::mutex> lk(gather_mutex());  // one clique user at a time
   for (int d : devs) SPV_TRY(use_device(d));         // fail early on a bad device number
   GatherCtx *ctx = nullptr;
-  SPV_TRY(gather_ctx_get(devs, (transport == SPV_GATHER_AUTO ? gather_transport(all_devs, total) : transport) == SPV_GATHER_RCCL, &ctx));
+  SPV_TRY(gather_ctx_get(devs, want_rccl, &ctx));
   const long long max_cnt = shard_lo(total, G, 1);   // = size of shard 0, the largest
   std::vector<BufList> bufs(G + 1);                  // [G] = the root's receive / staging buffers
   std::vector<std::vector<const void *>> send(K, std::vector<const void *>(G, nullptr));
