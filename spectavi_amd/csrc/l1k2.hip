@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kThreads, 3) void l1k2_tile_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// Wide rows (256 < dim <= 2048, zero padded to a multiple of 128 bytes): a row no longer fits the
+// Wide rows (256 < dim <= 2048, any multiple of 16 bytes): a row no longer fits the
 // register file next to a second one, so the roles of the tile kernel are kept but the row is
 // consumed in 128-byte chunks.  A workgroup stages kWideRows database rows (full width) in LDS;
 // for every chunk each lane fetches that chunk of its Q query rows (one 128-byte line per query,
@@ -328,7 +328,8 @@ __global__ __launch_bounds__(kThreads, 2) void l1k2_wide_kernel(const uint4 *__r
     for (int r = 0; r < kWideRows; ++r)
 #pragma unroll
       for (int q = 0; q < Q; ++q) acc[r][q] = 0;
-    for (int c4 = 0; c4 < V4; c4 += kWideChunk4 / 4) {
+    const int V4full = V4 / (kWideChunk4 / 4) * (kWideChunk4 / 4);
+    for (int c4 = 0; c4 < V4full; c4 += kWideChunk4 / 4) {
       uint32_t qreg[Q][kWideChunk4];
 #pragma unroll
       for (int q = 0; q < Q; ++q)
@@ -354,6 +355,24 @@ __global__ __launch_bounds__(kThreads, 2) void l1k2_wide_kernel(const uint4 *__r
           for (int q = 0; q < Q; ++q) acc[r][q] = __builtin_amdgcn_sad_u8(qreg[q][4 * v + 2], xr.z, acc[r][q]);
 #pragma unroll
           for (int q = 0; q < Q; ++q) acc[r][q] = __builtin_amdgcn_sad_u8(qreg[q][4 * v + 3], xr.w, acc[r][q]);
+        }
+      }
+    }
+    // ragged end of the row (dim is a multiple of 16, not of 128): one 16-byte group at a time, same
+    // roles -- round 3; before, such rows were zero padded to whole chunks (dim 272 paid for 384)
+    for (int v4 = V4full; v4 < V4; ++v4) {
+      uint4 qw[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) qw[q] = yq[q][v4];
+#pragma unroll
+      for (int r = 0; r < kWideRows; ++r) {
+        const uint4 xr = wtile[r * V4 + v4];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          acc[r][q] = __builtin_amdgcn_sad_u8(qw[q].x, xr.x, acc[r][q]);
+          acc[r][q] = __builtin_amdgcn_sad_u8(qw[q].y, xr.y, acc[r][q]);
+          acc[r][q] = __builtin_amdgcn_sad_u8(qw[q].z, xr.z, acc[r][q]);
+          acc[r][q] = __builtin_amdgcn_sad_u8(qw[q].w, xr.w, acc[r][q]);
         }
       }
     }
@@ -485,7 +504,7 @@ static int pick_dim_pad(int dim) {
   static const int kDims[] = {64, 128, 144, 192, 256};
   for (int d : kDims)
     if (dim <= d) return d;
-  return dim <= kMaxGenericDim ? (dim + 127) / 128 * 128 : -1;  // wide-row kernel: whole 128-byte chunks
+  return dim <= kMaxGenericDim ? dim : -1;  // wide-row kernel: any multiple of 16 bytes (whole 128-byte chunks + a ragged end)
 }
 
 L1K2Plan l1k2_plan(int xrows, int yrows, int dim) {
@@ -576,7 +595,7 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
     case 192: launch_tile_q<48>(kx, ky, xrows, yrows, p, part, stream); break;
     case 256: launch_tile_q<64>(kx, ky, xrows, yrows, p, part, stream); break;
     default: {
-      if (p.dim_pad <= 256 || p.dim_pad > kMaxGenericDim || p.dim_pad % 128)
+      if (p.dim_pad <= 256 || p.dim_pad > kMaxGenericDim || p.dim_pad % 16)
         return set_error(SPV_ERR_INVALID, "internal: bad dim_pad %d", p.dim_pad);
       const size_t lds = (size_t)kWideRows * p.dim_pad;
       const dim3 grid((unsigned)((p.qblocks + 7) / 8 * 8 * p.slices));  // decoded XCD-aware in the kernel

@@ -46,7 +46,8 @@ def test_golden_through_reference_symbol(golden, name):
     (65, 1, 128, 256), (63, 257, 128, 3), (1, 1, 16, 256), (2, 3, 32, 256),
     (130, 70, 64, 2), (500, 300, 48, 256), (300, 100, 80, 256), (300, 100, 160, 256),
     (300, 100, 192, 256), (300, 100, 208, 256), (300, 100, 256, 256),
-    (300, 100, 272, 256), (200, 130, 512, 256), (150, 70, 2048, 256),   # generic-width fallback kernel
+    (300, 100, 272, 256), (200, 130, 512, 256), (150, 70, 2048, 256),   # wide-row kernel: whole chunks and a ragged end
+    (4100, 700, 400, 256), (900, 333, 1040, 7), (513, 257, 2032, 256), (77, 600, 288, 256),
     (70000, 300, 128, 256),   # more than one 65536-row slice limit worth of rows
     (4096, 5000, 128, 2),     # tie-heavy at a size with several slices
 ])
