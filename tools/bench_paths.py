@@ -183,8 +183,9 @@ def l1k2_shapes(steps, warmup):
     """Other descriptor widths and small problems (device-resident, kernel + merge)."""
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(11)
+    extra = tuple((65536, int(d)) for d in os.environ.get("SPECTAVI_BENCH_DIMS", "").split(",") if d)
     for rows, dim in ((262144, 64), (262144, 144), (262144, 192), (262144, 256), (65536, 272), (65536, 400), (65536, 512),
-                      (1000, 128), (10000, 128)):
+                      (1000, 128), (10000, 128)) + extra:
         x = torch.randint(0, 256, (rows, dim), dtype=torch.uint8, device=dev, generator=g)
         y = torch.randint(0, 256, (rows, dim), dtype=torch.uint8, device=dev, generator=g)
         _, dt = timed(lambda: spv.l1k2(x, y), steps, warmup)
