@@ -211,11 +211,12 @@ __global__ __launch_bounds__(kThreads, 3) void l1k2_tile_kernel(
     const uint4 *buf = tile[tl & 1];
     const uint32_t jbase = (uint32_t)(row0 - row_begin);
 
-    if constexpr (D4 >= 48) {
+    if constexpr (D4 >= 40) {
       // wide rows: NCH chunks per row, the next chunk's LDS reads issued before the current
       // chunk's SAD chain (xa / xb alternate; the last chunk prefetches the next row's first)
       constexpr int NCH = D4 >= 64 ? 4 : 2;
       constexpr int CV = V4 / NCH;
+      static_assert(V4 % NCH == 0, "the row must split into NCH chunks of whole 16-byte vectors");
       uint4 xa[CV], xb[CV];
       lds_row<CV>(xa, buf);
       for (int r = 0; r < nrows; ++r) {
@@ -501,9 +502,10 @@ int max_q_for(int dim_pad) { return dim_pad <= 64 ? 4 : 2; }
 
 // Kernel row widths that are instantiated; other dims are zero-padded up.
 static int pick_dim_pad(int dim) {
-  static const int kDims[] = {64, 128, 144, 192, 256};
-  // (un-instantiated widths below 256 are better off padded than in the wide kernel unpadded:
-  // measured 0.55-0.80 of the SAD peak on the true width against 0.51-0.64, dims 48..240)
+  static const int kDims[] = {32, 48, 64, 80, 96, 112, 128, 144, 160, 192, 256};
+  // (widths below 256 that are not instantiated are better off padded to the next one than in the wide
+  // kernel unpadded: measured 0.55-0.80 of the SAD peak on the true width against 0.51-0.64, dims 48..240,
+  // when only {64, 128, 144, 192, 256} existed)
   for (int d : kDims)
     if (dim <= d) return d;
   return dim <= kMaxGenericDim ? dim : -1;  // wide-row kernel: any multiple of 16 bytes (whole 128-byte chunks + a ragged end)
@@ -591,9 +593,15 @@ int l1k2_run(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows, int d
   {
     ProfScope prof("l1k2_tile", stream);
   switch (p.dim_pad) {
+    case 32: launch_tile_q<8>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 48: launch_tile_q<12>(kx, ky, xrows, yrows, p, part, stream); break;
     case 64: launch_tile_q<16>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 80: launch_tile_q<20>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 96: launch_tile_q<24>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 112: launch_tile_q<28>(kx, ky, xrows, yrows, p, part, stream); break;
     case 128: launch_tile_q<32>(kx, ky, xrows, yrows, p, part, stream); break;
     case 144: launch_tile_q<36>(kx, ky, xrows, yrows, p, part, stream); break;
+    case 160: launch_tile_q<40>(kx, ky, xrows, yrows, p, part, stream); break;
     case 192: launch_tile_q<48>(kx, ky, xrows, yrows, p, part, stream); break;
     case 256: launch_tile_q<64>(kx, ky, xrows, yrows, p, part, stream); break;
     default: {

@@ -46,6 +46,7 @@ def test_golden_through_reference_symbol(golden, name):
     (65, 1, 128, 256), (63, 257, 128, 3), (1, 1, 16, 256), (2, 3, 32, 256),
     (130, 70, 64, 2), (500, 300, 48, 256), (300, 100, 80, 256), (300, 100, 160, 256),
     (300, 100, 192, 256), (300, 100, 208, 256), (300, 100, 256, 256),
+    (3000, 700, 96, 256), (2500, 900, 112, 256), (1200, 1300, 224, 256), (5000, 520, 160, 3), (700, 4100, 80, 256),   # every instantiated width
     (300, 100, 272, 256), (200, 130, 512, 256), (150, 70, 2048, 256),   # wide-row kernel: whole chunks and a ragged end
     (4100, 700, 400, 256), (900, 333, 1040, 7), (513, 257, 2032, 256), (77, 600, 288, 256),
     (70000, 300, 128, 256),   # more than one 65536-row slice limit worth of rows
