@@ -82,3 +82,23 @@ def test_parent_does_not_import_torch():
     assert r.returncode == 0, r.stderr
     assert "LAUNCH 2 ['--gpus', '2', '--steps', '1']" in r.stdout
     assert "torch" not in r.stderr
+
+
+def test_roofline_arithmetic_matches_survey_8d():
+    """achieved = pairs/s x 32 v_sad lane-ops / (CUs x 64 x f_clk); the BASELINE reading
+    streams 128 B per pair against 8 TB/s; compulsory bytes (N + M) x 128 + 24 N."""
+    a = bench.parse_args([])
+    r = bench.roofline_of(a, launches=4, tile_ms=4 * 900.0, merge_ms=4 * 0.05)
+    pairs_per_s = 1e12 / 0.9
+    assert abs(r["achieved"] - pairs_per_s * 32 / 1e12) < 1e-6
+    assert abs(r["peak"] - 256 * 64 * 2.4e9 / 1e12) < 1e-9 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["avg_launch_ms"] - 900.0) < 1e-9 and r["launches_timed"] == 4
+    assert abs(r["hbm_streaming_equiv"]["achieved"] - pairs_per_s * 128 / 1e9) < 1e-3
+    assert r["hbm_compulsory"]["bytes"] == (1_000_000 + 1_000_000) * 128 + 24 * 1_000_000
+    assert r["bound"] == "valu" and r["kernel"] == "l1k2_tile_kernel"
+
+
+def test_host_cpu_reports_model_and_counts():
+    model, physical, logical = bench.host_cpu()
+    assert isinstance(model, str) and model and logical == os.cpu_count()
+    assert physical is None or 1 <= physical <= logical
