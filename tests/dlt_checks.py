@@ -130,9 +130,11 @@ def check_definition(X, P0, P1, x, xp, err=None, what="X", unfused=False):
 
 def check_against_oracle(X, oX, P0, P1, x, xp, what="X"):
     """X (HIP, sign canonicalised) against the oracle's V.col(3) (Eigen-style JacobiSVD restatement,
-    sign as it falls): equal up to sign within (64 eps sigma1 + 4 |dA|) / (sigma3 - sigma4) on the
-    well-separated finite points, dA being the rounding of the unfused formation of A (see
-    dlt_matrices).  Returns the worst ratio to that tolerance."""
+    sign as it falls): equal up to sign within (64 eps sigma1 + 8 |dA|) / (sigma3 - sigma4) on the
+    well-separated finite points, dA being one rounding of the formation of A (see dlt_matrices): the
+    oracle rounds the product u P[2,c] before the subtraction (4 |dA| covered it through round 2), the
+    kernel since round 3 forms u = x0 rcp(x2), up to 1.5 ulp from the quotient (fuzz seed 20261004,
+    case 5249: 3.4e-14 against 3.1e-14 at 4 |dA|).  Returns the worst ratio to that tolerance."""
     X, oX = np.asarray(X, np.float64), np.asarray(oX, np.float64)
     A, _, formation = dlt_matrices(P0, P1, x, xp, return_formation_error=True)
     S, _, ok = lapack_svd(A)
@@ -142,8 +144,8 @@ def check_against_oracle(X, oX, P0, P1, x, xp, what="X"):
         return 0.0
     sgn = np.sign(np.einsum("ni,ni->n", X[ok], oX[ok]))
     diff = np.max(np.abs(X[ok] - sgn[:, None] * oX[ok]), axis=1)
-    # 64 eps sigma1 / gap for the two solvers + the oracle's unfused rounding of A itself
-    tol = (64 * np.finfo(np.float64).eps * S[ok, 0] + 4 * formation[ok]) / (S[ok, 2] - S[ok, 3]) + 1e-15
+    # 64 eps sigma1 / gap for the two solvers + both sides' rounding of the formation of A
+    tol = (64 * np.finfo(np.float64).eps * S[ok, 0] + 8 * formation[ok]) / (S[ok, 2] - S[ok, 3]) + 1e-15
     worst = float(np.max(diff / tol))
     assert worst <= 1.0, "%s: differs from the JacobiSVD oracle by %.3e (tol %.3e)" % (
         what, diff[np.argmax(diff / tol)], tol[np.argmax(diff / tol)])
