@@ -89,7 +89,7 @@ inline void null_jacobi(const double (&A0)[4][4], double (&xv)[4]) {
 // (modified Gram-Schmidt, no pivoting), so A^T A = U^T D U; the smallest right singular vector
 // of A by inverse iteration on U^T D U, the diagonal solve scaled by d_3 (y_j = z_j d_3 / d_j,
 // y_3 = z_3), iterates left un-normalised, convergence = direction of consecutive iterates equal
-// to 1e-12 (same schedule as the HIP kernel: steps 0, 1, 2, then tested steps 3..7).  Returns false
+// to 1e-13 (same schedule as the HIP kernel: steps 0, 1, 2, then tested steps 3..7).  Returns false
 // when the last step still moved the direction or the iterate left the range -- the caller then
 // falls back to method 1.
 inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4]) {
@@ -149,7 +149,7 @@ inline bool null_gs_inverse_iteration(const double (&A0)[4][4], double (&xv)[4])
     const double bw = maxabs(w);
     double e[4];
     for (int c = 0; c < 4; ++c) e[c] = std::fabs(std::fma(w[c], bv, -(v[c] * bw)));
-    const double bound = 1e-12 * (bw * bv);
+    const double bound = 1e-13 * (bw * bv);
     ok = (maxabs(e) <= bound) && (bound >= 1e-290) && (bound <= 1e290);
     for (int c = 0; c < 4; ++c) v[c] = w[c];
     bv = bw;

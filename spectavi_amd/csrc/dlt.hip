@@ -154,10 +154,13 @@ __device__ __forceinline__ void null_jacobi(const double (&A0)[4][4], double (&x
 // 1/sigma4^2 per step (d_3 >= sigma4^2 is the squared distance of the last column from the span of
 // the others: the growth per step is d_3 / sigma4^2, O(1) for a consistent point), and the
 // convergence test compares DIRECTIONS of consecutive un-normalised iterates,
-//   max_i |w_i max|v| - v_i max|w|| <= 1e-12 max|v| max|w|
+//   max_i |w_i max|v| - v_i max|w|| <= 1e-13 max|v| max|w|
 // (no sign ambiguity: (A^T A)^-1 is positive definite).  Steps 0 (a bare back-substitution from
 // e4), 1 and 2 run unconditionally, then a point stops at the first step that moved its direction
-// by no more than 1e-12 (step 3 for pixel noise 1e-3; at most 8).  ~300 fp64 instructions.
+// by no more than 1e-13 (step 3 for pixel noise 1e-3; at most 8): what is left of the direction error
+// is then 1e-13 rho / (1 - rho), rho = (sigma4/sigma3)^2 the contraction (1e-12 until fuzz seed
+// 20261004 case 5249 -- an inconsistent pair, rho = 0.036 -- came out 3.4e-14 from the oracle).
+// ~300 fp64 instructions.
 // Returns false when the last step still moved it (ill-separated sigma3, sigma4), or the
 // iterate left the range (inf / nan from a degenerate A, overflow of a badly conditioned one);
 // the caller then falls back to method 1.
@@ -229,7 +232,7 @@ __device__ __forceinline__ bool null_gs_inverse_iteration(const double (&A0)[4][
     const double bw = fmax(fmax(fabs(w0), fabs(w1)), fmax(fabs(w2), fabs(w3)));
     const double e0 = fabs(__builtin_fma(w0, bv, -(v0 * bw))), e1 = fabs(__builtin_fma(w1, bv, -(v1 * bw)));
     const double e2 = fabs(__builtin_fma(w2, bv, -(v2 * bw))), e3 = fabs(__builtin_fma(w3, bv, -(v3 * bw)));
-    const double bound = 1e-12 * (bw * bv);
+    const double bound = 1e-13 * (bw * bv);
     // a bound of 0 or inf is an iterate out of range, never agreement
     ok = (fmax(fmax(e0, e1), fmax(e2, e3)) <= bound) && (bound >= 1e-290) && (bound <= 1e290);
     v0 = w0;
