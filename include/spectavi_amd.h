@@ -335,6 +335,19 @@ int spv_l1k2_device(const uint8_t *d_x, const uint8_t *d_y, int xrows, int yrows
 int spv_l1k2_gathered_device(int ndev, const int *devices, const uint8_t *const *d_x,
                              const uint8_t *const *d_y, int xrows, long long yrows_total, int dim,
                              uint64_t *d_idx, int32_t *d_dist, int transport);
+/* The same for the cascade hash (every device also holds a replica of the hyperplanes d_dict[r],
+ * float32[n,dim,m], and rebuilds identical codes and bucket tables; d_ncand int32[yrows_total] on
+ * devices[0], may be NULL) and for the DLT (point shards d_x[r], d_xp[r] double[cnt_r,3]; d_dst on
+ * devices[0]: double[npt_total,4], or double[npt_total] with want_error != 0; 32 or 8 bytes per point
+ * travel, already in the ABI layout).  Loops sharded: src/CascadingHashNn.h:229-245 (the query loop of
+ * its BruteForceNnL1K2 with SetFilter), src/Spectavi.cpp:48-51 / :64-67. */
+int spv_cascade_gathered_device(int ndev, const int *devices, const float *const *d_x,
+                                const float *const *d_y, int xrows, long long yrows_total, int dim, int m,
+                                int n, int g, const float *const *d_dict, uint64_t *d_idx, float *d_dist,
+                                int32_t *d_ncand, int transport);
+int spv_dlt_gathered_device(int ndev, const int *devices, const double *P0, const double *P1,
+                            long long npt_total, const double *const *d_x, const double *const *d_xp,
+                            double *d_dst, int want_error, int transport);
 /* First row of shard r of `total` rows over `shards` contiguous balanced shards (r = shards: total). */
 long long spv_shard_lo(long long total, int shards, int r);
 

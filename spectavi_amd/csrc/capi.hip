@@ -1294,6 +1294,68 @@ int device_l1k2_gathered(const std::vector<int> &devs, const uint8_t *const *d_x
   return run_gathered(devs, yrows, {sizeof(Record)}, produce, consume, transport);
 }
 
+// Cascade hash and DLT with everything resident, the same way: per-device replicas of the database
+// and of the hyperplanes (every rank rebuilds identical codes and bucket tables), query / point shards
+// per device, results gathered and (cascade) widened on devs[0].
+int device_cascade_gathered(const std::vector<int> &devs, const float *const *d_x, const float *const *d_y,
+                            int xrows, long long yrows, int dim, int m, int n, int g, const float *const *d_dict,
+                            uint64_t *d_idx, float *d_dist, int32_t *d_ncand, int transport) {
+  auto produce = [&](int r, long long lo, long long hi, long long max_cnt, hipStream_t st, BufList &b,
+                     std::vector<const void *> &send) {
+    const int cnt = (int)(hi - lo);
+    const size_t wsb = cascade_workspace_bytes(xrows, cnt, dim, m, n, g);
+    DevBuf *di, *dds, *dn, *ws, *rec;
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(uint64_t), &di));
+    SPV_TRY(b.add((size_t)cnt * 2 * sizeof(float), &dds));
+    SPV_TRY(b.add((size_t)max_cnt * sizeof(int32_t), &dn));
+    SPV_TRY(b.add(wsb, &ws));
+    SPV_TRY(b.add((size_t)max_cnt * sizeof(Record), &rec));
+    SPV_TRY(cascade_run(d_x[r], d_y[r], xrows, cnt, dim, m, n, g, d_dict[r], di->as<uint64_t>(), dds->as<float>(),
+                        d_ncand ? dn->as<int32_t>() : nullptr, ws->p, wsb, st));
+    SPV_TRY(gather_pack_run(di->as<uint64_t>(), dds->p, cnt, rec->p, st));  // float32 distances as their bits
+    send[0] = rec->p;
+    if (d_ncand) send[1] = dn->p;
+    return SPV_OK;
+  };
+  auto consume = [&](const std::vector<const void *> &recv, int G, long long max_cnt, hipStream_t st, BufList &) {
+    SPV_TRY(gather_widen_run(recv[0], yrows, G, max_cnt, d_idx, d_dist, st));
+    if (d_ncand)
+      for (int r = 0; r < G; ++r) {  // the shards' segments to their slices of the root's array
+        const long long lo = shard_lo(yrows, G, r), hi = shard_lo(yrows, G, r + 1);
+        SPV_HIP_CHECK(hipMemcpyAsync(d_ncand + lo, static_cast<const int32_t *>(recv[1]) + (size_t)r * max_cnt,
+                                     (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+      }
+    return SPV_OK;
+  };
+  std::vector<size_t> rows = {sizeof(Record)};
+  if (d_ncand) rows.push_back(sizeof(int32_t));
+  return run_gathered(devs, yrows, rows, produce, consume, transport);
+}
+
+int device_dlt_gathered(const std::vector<int> &devs, const double *P0, const double *P1, long long npt,
+                        const double *const *d_x, const double *const *d_xp, double *d_dst, bool want_error,
+                        int transport) {
+  const size_t row = (want_error ? 1 : 4) * sizeof(double);
+  auto produce = [&](int r, long long lo, long long hi, long long max_cnt, hipStream_t st, BufList &b,
+                     std::vector<const void *> &send) {
+    DevBuf *dd;
+    SPV_TRY(b.add((size_t)max_cnt * row, &dd));
+    SPV_TRY(dlt_run(P0, P1, hi - lo, d_x[r], d_xp[r], dd->as<double>(), want_error, st));
+    send[0] = dd->p;
+    return SPV_OK;
+  };
+  auto consume = [&](const std::vector<const void *> &recv, int G, long long max_cnt, hipStream_t st, BufList &) {
+    for (int r = 0; r < G; ++r) {  // rows are already in the ABI layout: shard segments to their slices
+      const long long lo = shard_lo(npt, G, r), hi = shard_lo(npt, G, r + 1);
+      SPV_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(d_dst) + (size_t)lo * row,
+                                   static_cast<const char *>(recv[0]) + (size_t)r * max_cnt * row,
+                                   (size_t)(hi - lo) * row, hipMemcpyDeviceToDevice, st));
+    }
+    return SPV_OK;
+  };
+  return run_gathered(devs, npt, {row}, produce, consume, transport);
+}
+
 int host_cascade_gathered(const std::vector<int> &devs, const float *x, const float *y, int xrows, int yrows,
                           int dim, int m, int n, int g, const float *dict, uint64_t *idx, float *dist,
                           int32_t *ncand) {
@@ -1868,6 +1930,50 @@ int spv_l1k2_gathered_device(int ndev, const int *devices, const uint8_t *const 
     }
     if (((uintptr_t)d_idx | (uintptr_t)d_dist) & 15) return set_error(SPV_ERR_INVALID, "device pointers must be 16-byte aligned");
     return device_l1k2_gathered(devs, d_x, d_y, xrows, yrows_total, dim, d_idx, d_dist, transport);
+  });
+}
+
+static int check_gathered_devices(int ndev, const int *devices, int transport) {
+  if (ndev < 1 || ndev > 64 || !devices) return set_error(SPV_ERR_INVALID, "bad device list");
+  if (transport != SPV_GATHER_RCCL && transport != SPV_GATHER_PEERCOPY)
+    return set_error(SPV_ERR_INVALID, "transport must be SPV_GATHER_RCCL or SPV_GATHER_PEERCOPY");
+  return SPV_OK;
+}
+
+int spv_cascade_gathered_device(int ndev, const int *devices, const float *const *d_x, const float *const *d_y,
+                                int xrows, long long yrows_total, int dim, int m, int n, int g,
+                                const float *const *d_dict, uint64_t *d_idx, float *d_dist, int32_t *d_ncand,
+                                int transport) {
+  clear_error();
+  return host_guard([&] {
+    SPV_TRY(check_gathered_devices(ndev, devices, transport));
+    if (!d_x || !d_y || !d_dict) return set_error(SPV_ERR_INVALID, "null pointer");
+    if (yrows_total < 0 || yrows_total > (long long)INT32_MAX * ndev) return set_error(SPV_ERR_INVALID, "bad row count");
+    SPV_TRY(check_cascade_args(xrows, 0, dim, m, n, g));
+    if (yrows_total == 0) return (int)SPV_OK;
+    if (!d_idx || !d_dist) return set_error(SPV_ERR_INVALID, "null pointer");
+    const int G = (int)std::min<long long>(ndev, yrows_total);
+    for (int r = 0; r < G; ++r)
+      if (!d_y[r] || !d_dict[r] || (xrows > 0 && !d_x[r])) return set_error(SPV_ERR_INVALID, "null pointer (rank %d)", r);
+    return device_cascade_gathered(std::vector<int>(devices, devices + ndev), d_x, d_y, xrows, yrows_total, dim, m, n, g,
+                                   d_dict, d_idx, d_dist, d_ncand, transport);
+  });
+}
+
+int spv_dlt_gathered_device(int ndev, const int *devices, const double *P0, const double *P1, long long npt_total,
+                            const double *const *d_x, const double *const *d_xp, double *d_dst, int want_error,
+                            int transport) {
+  clear_error();
+  return host_guard([&] {
+    SPV_TRY(check_gathered_devices(ndev, devices, transport));
+    if (npt_total < 0) return set_error(SPV_ERR_INVALID, "negative point count");
+    if (npt_total == 0) return (int)SPV_OK;
+    if (!P0 || !P1 || !d_x || !d_xp || !d_dst) return set_error(SPV_ERR_INVALID, "null pointer");
+    const int G = (int)std::min<long long>(ndev, npt_total);
+    for (int r = 0; r < G; ++r)
+      if (!d_x[r] || !d_xp[r]) return set_error(SPV_ERR_INVALID, "null pointer (rank %d)", r);
+    return device_dlt_gathered(std::vector<int>(devices, devices + ndev), P0, P1, npt_total, d_x, d_xp, d_dst,
+                               want_error != 0, transport);
   });
 }
 

@@ -147,6 +147,72 @@ def l1k2_gathered(xs, ys, transport="rccl"):
     return idx, dist
 
 
+def _gather_lists(G, per_rank, total):
+    if [int(t.shape[0]) for t in per_rank] != [b - a for a, b in zip(shard_bounds(total, G)[:-1], shard_bounds(total, G)[1:])]:
+        raise ValueError("the per-GPU shards must be the contiguous balanced split of the %d rows" % total)
+    for t in per_rank:
+        torch.cuda.synchronize(t.device)  # the library runs on streams of its own
+
+
+def cascade_gathered(xs, ys, dicts, g=2, transport="rccl", want_ncand=False):
+    """nn_cascading_hash sharded inside ONE process with everything resident: per GPU a
+    replica of the database xs[r] and of the hyperplanes dicts[r] (float32 [n,D,m]) and the query shard
+    ys[r]; results gathered (16-byte records, ncand as int32) and widened on ys[0]'s GPU."""
+    G = len(xs)
+    if not (G == len(ys) == len(dicts)) or not xs:
+        raise ValueError("one database replica, one dictionary replica and one query shard per GPU")
+    for x, y, d in zip(xs, ys, dicts):
+        _need(x, torch.float32, "x")
+        _need(y, torch.float32, "y")
+        _need(d, torch.float32, "hash_dict")
+        if not (x.device == y.device == d.device):
+            raise ValueError("the tensors of one rank must share a GPU")
+    xrows, dim = xs[0].shape
+    n, ddim, m = dicts[0].shape
+    total = sum(int(y.shape[0]) for y in ys)
+    _gather_lists(G, ys, total)
+    root = ys[0].device
+    idx = torch.empty((total, 2), dtype=torch.int64, device=root)
+    dist = torch.empty((total, 2), dtype=torch.float32, device=root)
+    ncand = torch.empty((total,), dtype=torch.int32, device=root) if want_ncand else None
+    devs = (ct.c_int * G)(*[y.device.index for y in ys])
+    vp = ct.c_void_p * G
+    clib.spv_cascade_gathered_device.restype = ct.c_int
+    clib.spv_cascade_gathered_device.argtypes = [ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p),
+                                                 ct.c_int, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int,
+                                                 ct.POINTER(ct.c_void_p), _vp, _vp, _vp, ct.c_int]
+    check(clib.spv_cascade_gathered_device(G, devs, vp(*[x.data_ptr() for x in xs]), vp(*[y.data_ptr() for y in ys]), xrows,
+                                           total, dim, m, n, g, vp(*[d.data_ptr() for d in dicts]), idx.data_ptr(),
+                                           dist.data_ptr(), ncand.data_ptr() if want_ncand else None,
+                                           {"rccl": 1, "copy": 2}[transport]))
+    return (idx, dist, ncand) if want_ncand else (idx, dist)
+
+
+def dlt_gathered(P0, P1, xs, xps, want_error=False, transport="rccl"):
+    """dlt_triangulate / dlt_reprojection_error sharded inside ONE process with the point shards
+    resident (xs[r], xps[r] float64 [cnt_r,3] on GPU r); rows gathered on xs[0]'s GPU."""
+    G = len(xs)
+    if G != len(xps) or not xs:
+        raise ValueError("one shard of each view per GPU")
+    for x, xp in zip(xs, xps):
+        _need(x, torch.float64, "x")
+        _need(xp, torch.float64, "xp")
+        if x.device != xp.device or x.shape != xp.shape:
+            raise ValueError("the two views of one rank must share a GPU and a shape")
+    total = sum(int(x.shape[0]) for x in xs)
+    _gather_lists(G, xs, total)
+    out = torch.empty((total, 1 if want_error else 4), dtype=torch.float64, device=xs[0].device)
+    devs = (ct.c_int * G)(*[x.device.index for x in xs])
+    vp = ct.c_void_p * G
+    clib.spv_dlt_gathered_device.restype = ct.c_int
+    clib.spv_dlt_gathered_device.argtypes = [ct.c_int, ct.POINTER(ct.c_int), _f64p, _f64p, ct.c_longlong,
+                                             ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p), _vp, ct.c_int, ct.c_int]
+    check(clib.spv_dlt_gathered_device(G, devs, np.ascontiguousarray(P0, np.float64), np.ascontiguousarray(P1, np.float64), total,
+                                       vp(*[x.data_ptr() for x in xs]), vp(*[xp.data_ptr() for xp in xps]), out.data_ptr(),
+                                       int(bool(want_error)), {"rccl": 1, "copy": 2}[transport]))
+    return out
+
+
 def cascade(x, y, hash_dict, g=2, workspace=None, want_ncand=False):
     """Cascade-hash 2-NN on device: x,y float32 [rows,D]; hash_dict float32 [n,D,m]."""
     _need(x, torch.float32, "x")

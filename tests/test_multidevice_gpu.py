@@ -326,6 +326,38 @@ def test_gathered_device_resident_form(oracle):
         device.l1k2_gathered([x, x], [torch.from_numpy(y[:3]).cuda(), torch.from_numpy(y[3:5]).cuda()], transport="rccl")
 
 
+def test_gathered_device_resident_cascade_and_dlt(oracle):
+    """spv_cascade_gathered_device / spv_dlt_gathered_device: the cascade hash and the DLT sharded inside
+    one process with replicas and shards resident -- a real RCCL clique of one and three ranks on
+    device 0 over peer copies with ragged shards; idx / dist / ncand bit-equal to the oracle, DLT rows
+    bit-equal to the one-device call."""
+    import torch
+    from spectavi_amd import device
+    rng = np.random.default_rng(78)
+    xf = rng.integers(-128, 128, (3001, 128)).astype(np.float32)
+    d = rng.standard_normal((2, 128, 8)).astype(np.float32)
+    tx, td = torch.from_numpy(xf).cuda(), torch.from_numpy(d).cuda()
+    P0, P1 = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    for nq, G, transport in ((1001, 1, "rccl"), (1001, 3, "copy"), (4, 3, "copy")):
+        yf = rng.integers(-128, 128, (nq, 128)).astype(np.float32)
+        yf[: nq // 2] = np.clip(xf[rng.integers(0, 3001, nq // 2)] + rng.integers(-2, 3, (nq // 2, 128)), -128, 127)
+        b = device.shard_bounds(nq, G)
+        ys = [torch.from_numpy(yf[b[r]:b[r + 1]].copy()).cuda() for r in range(G)]
+        idx, dist, ncand = device.cascade_gathered([tx] * G, ys, [td] * G, g=2, transport=transport, want_ncand=True)
+        oidx, odist, oncand, _ = oracle.nn_cascading_hash(xf, yf, 8, 2, 2, d)
+        assert np.array_equal(idx.cpu().numpy().view(np.uint64), oidx) and np.array_equal(dist.cpu().numpy(), odist)
+        assert np.array_equal(ncand.cpu().numpy(), oncand)
+        Xw = rng.standard_normal((nq, 4))
+        x, xp = Xw @ P0.T, Xw @ P1.T
+        xs = [torch.from_numpy(x[b[r]:b[r + 1]].copy()).cuda() for r in range(G)]
+        xps = [torch.from_numpy(xp[b[r]:b[r + 1]].copy()).cuda() for r in range(G)]
+        one = device.dlt_triangulate(P0, P1, torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda())
+        onee = device.dlt_reprojection_error(P0, P1, torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda())
+        assert torch.equal(device.dlt_gathered(P0, P1, xs, xps, transport=transport), one)
+        assert torch.equal(device.dlt_gathered(P0, P1, xs, xps, want_error=True, transport=transport).reshape(-1), onee.reshape(-1))
+        dc.check_against_oracle(one.cpu().numpy(), oracle.dlt_triangulate(P0, P1, x, xp), P0, P1, x, xp, what="gathered dlt")
+
+
 def _hip_rank(rank, world, port, nq, out_path):
     """One of `world` processes sharing GPU 0: HIP local compute on its query shard, the records
     gathered over gloo (RCCL cannot span ranks that share one device)."""
