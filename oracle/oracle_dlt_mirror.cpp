@@ -24,7 +24,8 @@ namespace {
 constexpr int kMaxSweeps = 30;
 
 struct Solve {
-  double X[4];
+  double X[4];   // unit norm, canonical sign
+  double S[4];   // the same direction at max-norm [0.5, 1), sign as it fell: what the error kernel uses
   double u, v, up, vp;
 };
 
@@ -197,6 +198,7 @@ inline void dlt_solve(const double *P0, const double *P1, const double *x, const
   const double q = 1.0 / std::sqrt(nrm2);
   const double scale = neg ? -q : q;
   for (int i = 0; i < 4; ++i) out.X[i] = sv[i] * scale;
+  for (int i = 0; i < 4; ++i) out.S[i] = sv[i];
   out.u = u;
   out.v = v;
   out.up = up;
@@ -213,9 +215,10 @@ inline void reproject(const double *P, const double *X, double *r) {
 
 // sum of the two image-plane residual norms (reference src/DltTriangulator.h:67-74), one reciprocal
 // per camera as the kernel; r0 / r1 = P X
-inline double reprojection_error(const double *P0, const double *P1, const Solve &s, double *r0, double *r1) {
-  reproject(P0, s.X, r0);
-  reproject(P1, s.X, r1);
+inline double reprojection_error(const double *P0, const double *P1, const Solve &s, double *r0, double *r1,
+                                 bool unit = true) {
+  reproject(P0, unit ? s.X : s.S, r0);
+  reproject(P1, unit ? s.X : s.S, r1);
   const double i0 = 1.0 / r0[2], i1 = 1.0 / r1[2];
   const double e0x = std::fma(r0[0], i0, -s.u), e0y = std::fma(r0[1], i0, -s.v);
   const double e1x = std::fma(r1[0], i1, -s.up), e1y = std::fma(r1[1], i1, -s.vp);
@@ -249,7 +252,7 @@ void oracle_dlt_mirror_reprojection_error(const double *P0, const double *P1, in
     Solve s;
     dlt_solve(P0, P1, x + 3 * (size_t)i, xp + 3 * (size_t)i, s);
     double r0[3], r1[3];
-    dst[i] = reprojection_error(P0, P1, s, r0, r1);
+    dst[i] = reprojection_error(P0, P1, s, r0, r1, /*unit=*/false);  // as dlt_kernel<true>: no normalisation
   }
 }
 

@@ -324,7 +324,9 @@ __device__ __forceinline__ double reprojection_error(const Cameras &cam, const d
 
 // FAST: method 2 with method 1 as fallback (consistent correspondences converge in 3-4 steps;
 // whatever does not within 8 takes the Jacobi); !FAST: method 1 only.
-template <bool FAST>
+// UNIT = false: X is only brought to max-norm [0.5, 1) by a power of two, neither normalised nor
+// sign-canonicalised -- enough for the reprojection error, which is a ratio of components of P X.
+template <bool FAST, bool UNIT = true>
 __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double x1, double x2,
                                           double y0, double y1, double y2, double (&X)[4],
                                           double &u, double &v, double &up, double &vp) {
@@ -334,7 +336,14 @@ __device__ __forceinline__ void dlt_solve(const Cameras &cam, double x0, double 
   bool done = false;
   if (FAST) done = null_gs_inverse_iteration(A, xv);
   if (!done) null_jacobi(A, xv);
-  dlt_finish(xv, X);
+  if (UNIT) {
+    dlt_finish(xv, X);
+  } else {
+    const double big = fmax(fmax(fabs(xv[0]), fabs(xv[1])), fmax(fabs(xv[2]), fabs(xv[3])));
+    const int ex = -__builtin_amdgcn_frexp_exp(big);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[i] = __builtin_amdgcn_ldexp(xv[i], ex);
+  }
 }
 
 // Persistent, barrier-free: every lane walks the points p, p + stride, ... and loads the six
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(kDltThreads) void dlt_kernel(Cameras cam, long long
       b2 = xp[3 * q + 2];
     }
     double X[4], u, v, up, vp;
-    dlt_solve<true>(cam, c0, c1, c2, d0, d1, d2, X, u, v, up, vp);
+    dlt_solve<true, !WANT_ERROR>(cam, c0, c1, c2, d0, d1, d2, X, u, v, up, vp);
     if (!WANT_ERROR) {
       double4 *o = reinterpret_cast<double4 *>(dst) + p;
       *o = make_double4(X[0], X[1], X[2], X[3]);
