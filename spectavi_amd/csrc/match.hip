@@ -12,8 +12,8 @@
 // reference's fancy indexing) never passes.  Output order = ascending query
 // index, exactly the order boolean-mask indexing produces.
 //
-// Three small kernels: per-block pass counts (wave ballots), an exclusive scan
-// of the block counts (one workgroup), an ordered scatter.
+// Three small kernels: per-block pass counts (wave ballots; a block takes 1024 queries, four per
+// lane), an exclusive scan of the block counts (one workgroup), an ordered scatter.
 
 #include "common.h"
 
@@ -21,24 +21,42 @@ namespace spv {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kPerThread = 4;                       // queries per lane: a block takes 1024 consecutive queries
+constexpr int kBlockQ = kThreads * kPerThread;
 
+// One 16-byte load for the index pair and one 8-byte load for the distance pair of a query
+// (round 3; before: three scalar loads per query at strides of 16 and 8 bytes).
 template <typename DistT>
-__device__ __forceinline__ bool passes(const uint64_t *idx, const DistT *dist, int q, double min_ratio) {
-  if (idx[2 * (size_t)q] == ~0ull) return false;
-  const double ratio = (double)dist[2 * (size_t)q + 1] / (double)dist[2 * (size_t)q];
+__device__ __forceinline__ bool passes(const uint64_t *idx, const DistT *dist, int q, double min_ratio, uint64_t &i0) {
+  const ulonglong2 id = reinterpret_cast<const ulonglong2 *>(idx)[q];
+  typedef DistT pair_t __attribute__((ext_vector_type(2)));
+  const pair_t d = reinterpret_cast<const pair_t *>(dist)[q];
+  i0 = id.x;
+  if (id.x == ~0ull) return false;
+  const double ratio = (double)d[1] / (double)d[0];
   return ratio >= min_ratio;
 }
 
+// Lane t of a block owns queries base + t + 256 k, k < 4 (coalesced loads per k); the pass flags of a
+// wave's four rounds are four ballots.  Output order = ascending query index: round k of wave w comes
+// after every earlier (k', w') pair of the block in (k, w) order, so the per-round ballot counts are
+// kept as a [4 rounds][4 waves] table.
 template <typename DistT>
 __global__ __launch_bounds__(kThreads) void ratio_count_kernel(const uint64_t *__restrict__ idx,
                                                                const DistT *__restrict__ dist, int n,
                                                                double min_ratio,
                                                                int *__restrict__ block_counts) {
   __shared__ int wsum[kThreads / 64];
-  const int q = blockIdx.x * kThreads + threadIdx.x;
-  const bool p = q < n && passes(idx, dist, q, min_ratio);
-  const unsigned long long bal = __ballot(p);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(bal);
+  const int base = blockIdx.x * kBlockQ;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int q = base + k * kThreads + threadIdx.x;
+    uint64_t i0;
+    const bool p = q < n && passes(idx, dist, q, min_ratio, i0);
+    cnt += __popcll(__ballot(p));
+  }
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
@@ -82,26 +100,37 @@ __global__ __launch_bounds__(kThreads) void ratio_scatter_kernel(const uint64_t 
                                                                  double min_ratio,
                                                                  const int *__restrict__ block_offsets,
                                                                  int *__restrict__ matches) {
-  __shared__ int wsum[kThreads / 64];
-  const int q = blockIdx.x * kThreads + threadIdx.x;
-  const bool p = q < n && passes(idx, dist, q, min_ratio);
-  const unsigned long long bal = __ballot(p);
+  __shared__ int wsum[kPerThread][kThreads / 64];
+  const int base = blockIdx.x * kBlockQ;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) wsum[w] = __popcll(bal);
+  bool p[kPerThread];
+  uint64_t i0[kPerThread];
+  unsigned long long bal[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int q = base + k * kThreads + threadIdx.x;
+    p[k] = q < n && passes(idx, dist, q, min_ratio, i0[k]);
+    bal[k] = __ballot(p[k]);
+    if (lane == 0) wsum[k][w] = __popcll(bal[k]);
+  }
   __syncthreads();
   int off = block_offsets[blockIdx.x];
-  for (int k = 0; k < w; ++k) off += wsum[k];
-  if (p) {
-    const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-    matches[2 * (size_t)pos + 0] = q;
-    matches[2 * (size_t)pos + 1] = (int)idx[2 * (size_t)q];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    int mine = off;
+    for (int ww = 0; ww < w; ++ww) mine += wsum[k][ww];
+    if (p[k]) {
+      const int pos = mine + __popcll(bal[k] & ((1ull << lane) - 1ull));
+      *reinterpret_cast<int2 *>(matches + 2 * (size_t)pos) = make_int2(base + k * kThreads + threadIdx.x, (int)i0[k]);
+    }
+    off += wsum[k][0] + wsum[k][1] + wsum[k][2] + wsum[k][3];
   }
 }
 
 }  // namespace
 
 size_t ratio_workspace_bytes(int yrows) {
-  const size_t blocks = ((size_t)std::max(yrows, 1) + kThreads - 1) / kThreads;
+  const size_t blocks = ((size_t)std::max(yrows, 1) + kBlockQ - 1) / kBlockQ;
   return round_up((blocks + 1) * sizeof(int), 256);
 }
 
@@ -117,8 +146,12 @@ int ratio_run(const uint64_t *d_idx, const void *d_dist, int dist_is_float, int 
   if (!d_idx || !d_dist || !d_matches) return set_error(SPV_ERR_INVALID, "null device pointer");
   if (!d_ws || ws_bytes < ratio_workspace_bytes(yrows))
     return set_error(SPV_ERR_INVALID, "workspace too small");
+  // rows are read as 16-byte (index pair) / 8-byte (distance pair) vectors, matches written as 8-byte pairs
+  if ((reinterpret_cast<uintptr_t>(d_idx) & 15) || (reinterpret_cast<uintptr_t>(d_dist) & 7) ||
+      (reinterpret_cast<uintptr_t>(d_matches) & 7))
+    return set_error(SPV_ERR_INVALID, "device pointers must be aligned to a row (idx 16, dist 8, matches 8 bytes)");
   int *counts = static_cast<int *>(d_ws);
-  const int blocks = (yrows + kThreads - 1) / kThreads;
+  const int blocks = (yrows + kBlockQ - 1) / kBlockQ;
   ProfScope prof("ratio_test", stream);
   if (dist_is_float) {
     const float *d = static_cast<const float *>(d_dist);
